@@ -1,0 +1,141 @@
+/* include/kpeg_hip.h -- C ABI of the MI355X (gfx950) decode path.
+ *
+ * This is the drop-in boundary for libKPEG's per-MCU hot loop.  The reference has
+ * no plugin/FFI interface; the seam these entry points replace is the pair of calls
+ *
+ *     decodeScanData();                          // src/Decoder.cpp:137  (:655-855)
+ *     m_image.createImageFromMCUs( m_MCU );      // src/Decoder.cpp:138  (src/Image.cpp:20-86)
+ *
+ * inside JPEGDecoder::decodeImageFile (src/Decoder.cpp:135-139), after the marker loop
+ * (:105-133) has filled m_QTables (include/Decoder.hpp:110), m_huffmanTable[2][2] (:117),
+ * the image dimensions and m_scanData (:125).  Everything below that seam --
+ * byteStuffScanData (:621-653), the Huffman bit loop (:694-803), HuffmanTree::contains
+ * (src/HuffmanTree.cpp:164-193), bitStringtoValue (src/Image.cpp:285-302),
+ * MCU::constructMCU / computeIDCT / performLevelShift / convertYCbCrToRGB
+ * (src/MCU.cpp:64-279) and the MCU tiling of Image::createImageFromMCUs -- runs on the
+ * GPU.  Output pixels are bit-identical to the reference's.
+ *
+ * Conventions: plain C, no exceptions across the boundary, 0 = success, negative =
+ * error (kpeg_hip_strerror).  The caller owns every buffer it passes.  A context is
+ * bound to one device and one stream and must be used from one host thread at a time.
+ * There is no CPU fallback: every entry point fails with KPEG_HIP_E_DEVICE if the GPU
+ * path cannot run.
+ */
+#ifndef KPEG_HIP_H
+#define KPEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPEG_HIP_ABI_VERSION 1
+
+enum {
+    KPEG_HIP_OK = 0,
+    KPEG_HIP_E_ARG = -1,      /* null pointer, zero size, dimensions not multiples of 8 ...  */
+    KPEG_HIP_E_DEVICE = -2,   /* HIP runtime error / no gfx950 device (message: last_error)  */
+    KPEG_HIP_E_TABLES = -3,   /* Huffman table is not a valid prefix code                    */
+    KPEG_HIP_E_STREAM = -4,   /* entropy-coded data ended early or held an invalid code      */
+    KPEG_HIP_E_NOMEM = -5,
+    KPEG_HIP_E_UNSUPPORTED = -6
+};
+
+typedef struct kpeg_hip_ctx kpeg_hip_ctx;
+
+/* kpeg::HuffmanTable (include/Types.hpp:116) flattened: counts[i] codes of length i+1,
+ * symbols in code order. */
+typedef struct {
+    uint8_t counts[16];
+    uint8_t symbols[256];
+} kpeg_dht;
+
+/* What the marker parser knows when it reaches the seam. */
+typedef struct {
+    uint32_t width, height;     /* SOF0 dimensions (Decoder.cpp:361); multiples of 8          */
+    uint16_t qt[2][64];         /* m_QTables[0], [1]: zig-zag order as stored (Decoder.cpp:278)
+                                   [0] -> Y, [1] -> Cb and Cr (hard-wired, MCU.cpp:110)       */
+    kpeg_dht dht[2][2];         /* m_huffmanTable[class 0=DC,1=AC][id]; id 0 -> Y,
+                                   id 1 -> Cb, Cr (hard-wired, Decoder.cpp:704)               */
+    uint32_t restart_interval;  /* MCUs per restart interval; 0 = a stream the reference
+                                   accepts (it rejects DRI)                    */
+} kpeg_frame;
+
+/* Per-call device timings (milliseconds, HIP events on the context's stream), valid after
+ * kpeg_hip_sync() when profiling is enabled.  0 for kernels that did not run. */
+typedef struct {
+    float unstuff_ms;      /* K0: FF00 removal / restart-segment scan                        */
+    float huff_sync_ms;    /* K1: self-synchronising sub-sequence decode (all rounds)        */
+    float huff_scan_ms;    /*     prefix sums between K1 and K2                              */
+    float huff_write_ms;   /* K2: coefficient-writing decode pass                            */
+    float dc_ms;           /* K3: DC prediction prefix sum + Q1                              */
+    float idct_ms;         /* K4: dequantise + IDCT + level shift + colour + tiled RGB store */
+    float total_ms;        /* first kernel start -> last kernel end                          */
+    uint32_t sync_rounds;  /* K1 rounds until every sub-sequence had synchronised            */
+    uint32_t exact_pixels; /* K4: pixels that took the reference-order re-evaluation         */
+} kpeg_hip_timings;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int kpeg_hip_abi_version(void);
+int kpeg_hip_create(kpeg_hip_ctx** ctx, int device);
+void kpeg_hip_destroy(kpeg_hip_ctx* ctx);
+const char* kpeg_hip_strerror(int code);
+const char* kpeg_hip_last_error(const kpeg_hip_ctx* ctx);
+/* Launch on a caller-owned hipStream_t (e.g. PyTorch's current stream); NULL = the
+ * context's own stream. */
+int kpeg_hip_set_stream(kpeg_hip_ctx* ctx, void* hip_stream);
+/* Wait for the context's stream and return the deferred status of the last *_dev call
+ * (kernels report corrupt entropy data through a device-side flag). */
+int kpeg_hip_sync(kpeg_hip_ctx* ctx);
+int kpeg_hip_set_profiling(kpeg_hip_ctx* ctx, int enable);
+int kpeg_hip_get_timings(kpeg_hip_ctx* ctx, kpeg_hip_timings* out);
+
+/* ---- host-buffer entry points (synchronous; H2D and D2H inside) ------------------------ */
+
+/* Replaces MCU::constructMCU's dequantise/de-zig-zag + computeIDCT + performLevelShift +
+ * convertYCbCrToRGB (MCU.cpp:110-279) + Image::createImageFromMCUs (Image.cpp:20-86) for a
+ * whole image whose Huffman decode was done by the caller.
+ *   coef: [mcu][comp 0..2][row u][col v] int16 -- the quantised (NOT dequantised) content
+ *         of MCU::m_8x8block just before MCU.cpp:110, i.e. natural order, absolute DC
+ *         (MCU.cpp:107-108), quirk Q1 applied (MCU.cpp:97-100).  mcu = tile row-major.
+ *   rgb : height*width*3 bytes, row-major R,G,B -- the bytes Image::dumpRawData writes
+ *         after its header (Image.cpp:129-135). */
+int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const int16_t* coef, uint8_t* rgb);
+
+/* Replaces decodeScanData() + createImageFromMCUs().
+ *   scan: the entropy-coded segment exactly as scanImageData collects it
+ *         (Decoder.cpp:544-574): every byte after the SOS header up to, not including,
+ *         the FF D9; still byte-stuffed. */
+int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len,
+                         uint8_t* rgb);
+
+/* `count` independent images of identical geometry and tables (throughput mode). */
+int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_frame* frame, const uint8_t* const* scans,
+                          const size_t* scan_lens, uint8_t* const* rgbs);
+
+/* ---- device-resident entry points (asynchronous on the context's stream) --------------- */
+/* All pointers are device pointers.  Errors found by kernels surface at kpeg_hip_sync(). */
+int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const int16_t* d_coef, uint8_t* d_rgb);
+int kpeg_hip_decode_scan_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* d_scan, size_t scan_len,
+                             uint8_t* d_rgb);
+/* Row-stripe sharding (frame->restart_interval must divide width/8 * k): decode only the
+ * MCU rows [first_mcu_row, first_mcu_row + mcu_rows) of the image.  d_scan holds the bytes
+ * of exactly those restart intervals (RSTn markers between them included); d_rgb receives
+ * mcu_rows*8 pixel rows.  One rank per GPU calls this on its stripe; the caller gathers. */
+int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* d_scan, size_t scan_len,
+                               uint32_t first_mcu_row, uint32_t mcu_rows, uint8_t* d_rgb);
+/* Entropy decode only: d_coef receives the coefficient layout of kpeg_hip_idct_colour. */
+int kpeg_hip_entropy_decode_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* d_scan, size_t scan_len,
+                                int16_t* d_coef);
+
+/* ---- knobs for tests and benchmarks ------------------------------------------------------- */
+/* IDCT kernel variant: 0 = fast path with exact re-evaluation of unsafe samples (default),
+ * 1 = reference-order evaluation of every sample (slow, used as an on-device cross-check). */
+int kpeg_hip_set_idct_mode(kpeg_hip_ctx* ctx, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPEG_HIP_H */

@@ -1,0 +1,179 @@
+"""libkpeg_amd -- Python plumbing over the MI355X-native libKPEG decode path.
+
+The product is the C-ABI library ``libkpeg_hip.so`` (include/kpeg_hip.h) plus the C++ host
+mirror of the reference's ``kpeg::JPEGDecoder`` / ``kpeg::Image`` API (``libkpeg.so`` and the
+``kpeg`` CLI).  This package only loads those libraries through ``ctypes`` for tests and
+``bench.py``; it contains no decode logic and no CPU fallback: if the HIP library is missing
+or no gfx950 device is present, it raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "libkpeg_hip.so")
+HOST_LIB = os.path.join(_HERE, "libkpeg.so")
+CLI = os.path.join(_HERE, "kpeg")
+
+OK = 0
+E_ARG, E_DEVICE, E_TABLES, E_STREAM, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+
+
+class KpegError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("kpeg_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Dht(ctypes.Structure):
+    _fields_ = [("counts", ctypes.c_uint8 * 16), ("symbols", ctypes.c_uint8 * 256)]
+
+
+class Frame(ctypes.Structure):
+    """kpeg_frame (include/kpeg_hip.h)."""
+    _fields_ = [
+        ("width", ctypes.c_uint32),
+        ("height", ctypes.c_uint32),
+        ("qt", (ctypes.c_uint16 * 64) * 2),
+        ("dht", (Dht * 2) * 2),
+        ("restart_interval", ctypes.c_uint32),
+    ]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in
+                ("unstuff_ms", "huff_sync_ms", "huff_scan_ms", "huff_write_ms", "dc_ms", "idct_ms", "total_ms")] + \
+               [("sync_rounds", ctypes.c_uint32), ("exact_pixels", ctypes.c_uint32)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = [
+    "kpeg_hip_abi_version", "kpeg_hip_create", "kpeg_hip_destroy", "kpeg_hip_strerror", "kpeg_hip_last_error",
+    "kpeg_hip_set_stream", "kpeg_hip_sync", "kpeg_hip_set_profiling", "kpeg_hip_get_timings",
+    "kpeg_hip_idct_colour", "kpeg_hip_decode_scan", "kpeg_hip_decode_batch",
+    "kpeg_hip_idct_colour_dev", "kpeg_hip_decode_scan_dev", "kpeg_hip_decode_stripe_dev",
+    "kpeg_hip_entropy_decode_dev", "kpeg_hip_set_idct_mode",
+]
+
+_lib = None
+
+
+def load_hip():
+    """dlopen libkpeg_hip.so and declare prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(HIP_LIB):
+        raise RuntimeError("%s is missing: run `python -m libkpeg_amd.build` (no CPU fallback exists)" % HIP_LIB)
+    # PyTorch ships its own libamdhip64.so.7.  Two HIP runtimes in one process cannot both open
+    # the GPU, so when PyTorch is installed it is imported first: libkpeg_hip.so (NEEDED
+    # libamdhip64.so.7) then binds to the copy PyTorch has already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = ctypes.CDLL(HIP_LIB)
+    vp, c_int, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    FP = ctypes.POINTER(Frame)
+    L.kpeg_hip_abi_version.restype = c_int
+    L.kpeg_hip_create.argtypes = [ctypes.POINTER(vp), c_int]
+    L.kpeg_hip_destroy.argtypes = [vp]
+    L.kpeg_hip_destroy.restype = None
+    L.kpeg_hip_strerror.argtypes = [c_int]
+    L.kpeg_hip_strerror.restype = ctypes.c_char_p
+    L.kpeg_hip_last_error.argtypes = [vp]
+    L.kpeg_hip_last_error.restype = ctypes.c_char_p
+    L.kpeg_hip_set_stream.argtypes = [vp, vp]
+    L.kpeg_hip_sync.argtypes = [vp]
+    L.kpeg_hip_set_profiling.argtypes = [vp, c_int]
+    L.kpeg_hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    L.kpeg_hip_set_idct_mode.argtypes = [vp, c_int]
+    L.kpeg_hip_idct_colour.argtypes = [vp, FP, vp, vp]
+    L.kpeg_hip_decode_scan.argtypes = [vp, FP, vp, sz, vp]
+    L.kpeg_hip_decode_batch.argtypes = [vp, c_int, FP, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp)]
+    L.kpeg_hip_idct_colour_dev.argtypes = [vp, FP, vp, vp]
+    L.kpeg_hip_decode_scan_dev.argtypes = [vp, FP, vp, sz, vp]
+    L.kpeg_hip_decode_stripe_dev.argtypes = [vp, FP, vp, sz, ctypes.c_uint32, ctypes.c_uint32, vp]
+    L.kpeg_hip_entropy_decode_dev.argtypes = [vp, FP, vp, sz, vp]
+    _lib = L
+    return L
+
+
+class Context:
+    """Thin RAII wrapper over kpeg_hip_ctx."""
+
+    def __init__(self, device=0):
+        self.lib = load_hip()
+        self._h = ctypes.c_void_p()
+        rc = self.lib.kpeg_hip_create(ctypes.byref(self._h), device)
+        if rc != OK:
+            raise KpegError(rc, "kpeg_hip_create(device=%d) failed: %s" % (device, self.lib.kpeg_hip_strerror(rc).decode()))
+
+    def close(self):
+        if self._h:
+            self.lib.kpeg_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise KpegError(rc, "%s (%s)" % (self.lib.kpeg_hip_strerror(rc).decode(),
+                                             self.lib.kpeg_hip_last_error(self._h).decode()))
+
+    # -- knobs
+    def set_stream(self, hip_stream):
+        self._chk(self.lib.kpeg_hip_set_stream(self._h, ctypes.c_void_p(hip_stream)))
+
+    def set_profiling(self, on):
+        self._chk(self.lib.kpeg_hip_set_profiling(self._h, int(bool(on))))
+
+    def set_idct_mode(self, mode):
+        self._chk(self.lib.kpeg_hip_set_idct_mode(self._h, mode))
+
+    def sync(self):
+        self._chk(self.lib.kpeg_hip_sync(self._h))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self.lib.kpeg_hip_get_timings(self._h, ctypes.byref(t)))
+        return t.asdict()
+
+    # -- host-buffer entry points
+    def idct_colour(self, frame, coef):
+        """coef: int16 array [nmcu, 3, 8, 8] (natural order, quantised). Returns HxWx3 uint8."""
+        coef = np.ascontiguousarray(coef, dtype=np.int16)
+        nmcu = (frame.width // 8) * (frame.height // 8)
+        assert coef.size == nmcu * 192, (coef.shape, nmcu)
+        rgb = np.empty((frame.height, frame.width, 3), np.uint8)
+        self._chk(self.lib.kpeg_hip_idct_colour(self._h, ctypes.byref(frame), coef.ctypes.data, rgb.ctypes.data))
+        return rgb
+
+    def decode_scan(self, frame, scan):
+        scan = np.frombuffer(scan, dtype=np.uint8) if not isinstance(scan, np.ndarray) else scan
+        rgb = np.empty((frame.height, frame.width, 3), np.uint8)
+        self._chk(self.lib.kpeg_hip_decode_scan(self._h, ctypes.byref(frame), scan.ctypes.data, scan.size, rgb.ctypes.data))
+        return rgb
+
+    # -- device-resident entry points (raw device pointers, e.g. torch tensors' data_ptr())
+    def idct_colour_dev(self, frame, d_coef, d_rgb):
+        self._chk(self.lib.kpeg_hip_idct_colour_dev(self._h, ctypes.byref(frame), ctypes.c_void_p(d_coef), ctypes.c_void_p(d_rgb)))
+
+    def decode_scan_dev(self, frame, d_scan, scan_len, d_rgb):
+        self._chk(self.lib.kpeg_hip_decode_scan_dev(self._h, ctypes.byref(frame), ctypes.c_void_p(d_scan), scan_len,
+                                                    ctypes.c_void_p(d_rgb)))
+
+    def decode_stripe_dev(self, frame, d_scan, scan_len, first_mcu_row, mcu_rows, d_rgb):
+        self._chk(self.lib.kpeg_hip_decode_stripe_dev(self._h, ctypes.byref(frame), ctypes.c_void_p(d_scan), scan_len,
+                                                      first_mcu_row, mcu_rows, ctypes.c_void_p(d_rgb)))
+
+    def entropy_decode_dev(self, frame, d_scan, scan_len, d_coef):
+        self._chk(self.lib.kpeg_hip_entropy_decode_dev(self._h, ctypes.byref(frame), ctypes.c_void_p(d_scan), scan_len,
+                                                       ctypes.c_void_p(d_coef)))

@@ -1,0 +1,87 @@
+"""Build recipe for the in-tree native libraries (driven by __graft_entry__.build()).
+
+    python -m libkpeg_amd.build          # everything
+    python -m libkpeg_amd.build hip      # only libkpeg_hip.so
+
+hipcc cross-compiles for gfx950 without a GPU; the .so files stay in-tree (git-ignored)
+so that they travel to the GPU box with the snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "libkpeg_amd")
+CSRC = os.path.join(PKG, "csrc")
+
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # bit-exactness contract: no FMA contraction anywhere; FMAs are written explicitly
+    "-ffp-contract=off",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, cwd=None):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=cwd)
+
+
+def build_hip(force=False):
+    out = os.path.join(PKG, "libkpeg_hip.so")
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(ROOT, "include", "kpeg_hip.h"))
+    if not force and not _newer(out, srcs):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    _run([hipcc] + HIP_FLAGS + ["-o", out, os.path.join(CSRC, "kpeg_hip.hip")])
+    return out
+
+
+def build_host(force=False):
+    """kpeg::JPEGDecoder / kpeg::Image host library and the `kpeg` CLI (C++, links libkpeg_hip)."""
+    host_dir = os.path.join(CSRC, "host")
+    if not os.path.isdir(host_dir):
+        return None
+    out = os.path.join(PKG, "libkpeg.so")
+    cli = os.path.join(PKG, "kpeg")
+    srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp") and f != "main.cpp"]
+    hdrs = [os.path.join(ROOT, "include", "kpeg", f) for f in os.listdir(os.path.join(ROOT, "include", "kpeg"))]
+    if force or _newer(out, srcs + hdrs):
+        _run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"),
+              "-I" + os.path.join(ROOT, "include", "kpeg"), "-o", out] + srcs +
+             ["-L" + PKG, "-lkpeg_hip", "-Wl,-rpath,$ORIGIN"])
+    main = os.path.join(host_dir, "main.cpp")
+    if os.path.exists(main) and (force or _newer(cli, [main, out])):
+        _run(["g++", "-O2", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"),
+              "-I" + os.path.join(ROOT, "include", "kpeg"), "-o", cli, main, "-L" + PKG, "-lkpeg", "-lkpeg_hip",
+              "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
+def build_oracle(force=False):
+    """The checker (CPU restatement) and, where /root/reference exists, the real reference."""
+    _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"])
+    if os.path.isdir("/root/reference"):
+        _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    _run(["make", "-s", "-C", os.path.join(ROOT, "tools"), "all"])
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_host(force)
+    build_oracle(force)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    {"hip": build_hip, "host": build_host, "oracle": build_oracle, "all": build_all}[what](True)
