@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native libKPEG decode path.
+
+Metric (BASELINE.json): Mpixels/s decoded, JFIF entropy-coded segment resident in HBM ->
+RGB8 resident in HBM, on the synthetic 7680x4320 4:4:4 baseline JPEG of SURVEY.md 8(d), plus
+the achieved HBM GB/s of the IDCT+colour kernel (K4) against the MI355X peak.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one full on-device decode (K0 unstuff, K1 sync, scan, K2 write, K4 IDCT+colour)
+of one image.  N > 1: weak scaling by row stripes -- the image is 7680 x (4320*N) with one
+restart interval per MCU row; rank r decodes MCU rows [540 r, 540 (r+1)) from the bytes of its
+own restart intervals, no data-path collective.  The RCCL gather of the RGB stripes to rank 0
+(the path's one exchange step) is timed separately and reported in the "gather" object; it is
+not part of `value` ("Multi-GPU").
+
+The JSON line also carries
+  roofline     K4: 9 algorithmic bytes per pixel (6 B int16 coefficients in + 3 B RGB out)
+               x pixels / K4's mean duration, measured with HIP events on the launch stream.
+  cpu_baseline the real reference decoder (oracle/_ref/kpeg_ref, built from /root/reference in
+               the build container; kind "reference") or, if that binary is absent, the CPU
+               restatement (kind "port"), timed on a bounded crop of the same synthetic field.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W8K, H8K = 7680, 4320
+SEED, QUALITY, SIGMA = 1234, 75, 6.0
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _synth():
+    so = os.path.join(ROOT, "tools", "libkpeg_synth.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "all"])
+    S = ctypes.CDLL(so)
+    S.kpeg_synth_jpeg_rows.restype = ctypes.c_size_t
+    S.kpeg_synth_jpeg_rows.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int,
+                                       ctypes.c_uint32, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    return S
+
+
+def synth_jpeg(w, h, y0=0, restart_interval=0, seed=SEED):
+    cap = w * h * 3 + (w * h) // 2 + 65536
+    buf = np.empty(cap, np.uint8)
+    n = _synth().kpeg_synth_jpeg_rows(w, h, y0, seed, QUALITY, restart_interval, SIGMA, 0, buf.ctypes.data, cap)
+    assert n > 0
+    return buf[:n].tobytes()
+
+
+def cpu_baseline(sample_w=2560, sample_h=1440):
+    """Reference CPU decoder on a bounded crop (top-left sample_w x sample_h of the 8K field)."""
+    data = synth_jpeg(sample_w, sample_h)
+    mp = sample_w * sample_h / 1e6
+    ref = os.path.join(ROOT, "oracle", "_ref", "kpeg_ref")
+    sample = "top-left %dx%d crop of the 7680x4320 synthetic field (seed %d, q%d), %.2f Mpixel" % (
+        sample_w, sample_h, SEED, QUALITY, mp)
+    if os.path.exists(ref):
+        d = tempfile.mkdtemp(prefix="kpegbench")
+        f = os.path.join(d, "sample.jpg")
+        with open(f, "wb") as fh:
+            fh.write(data)
+        out = subprocess.run([ref, "decode", f], capture_output=True, text=True, timeout=600)
+        try:
+            info = json.loads(out.stdout.strip().splitlines()[-1])
+            if info.get("status") == "DECODE_DONE":
+                return {"value": round(info["mpix_per_s"], 4), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                        "sample": sample + "; libKPEG's own decoder (oracle/_ref), 1 thread as shipped"}
+        except Exception:
+            pass
+        finally:
+            import shutil
+            shutil.rmtree(d, ignore_errors=True)
+    # fall back to the CPU restatement (still only a baseline, never the product path)
+    so = os.path.join(ROOT, "oracle", "libkpeg_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"])
+    L = ctypes.CDLL(so)
+    L.kpeg_oracle_decode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                     ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+    rgb = ctypes.POINTER(ctypes.c_uint8)()
+    w, h = ctypes.c_uint32(), ctypes.c_uint32()
+    t0 = time.perf_counter()
+    st = L.kpeg_oracle_decode(data, len(data), ctypes.byref(rgb), ctypes.byref(w), ctypes.byref(h), 1)
+    dt = time.perf_counter() - t0
+    assert st == 4
+    return {"value": round(mp / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": sample + "; oracle/kpeg_oracle.c (cos table precomputed, zero terms skipped), 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=W8K)
+    ap.add_argument("--height", type=int, default=H8K, help="rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--idct-only", action="store_true", help="time K4 alone on resident coefficients (BASELINE config 2 style)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import libkpeg_amd as K
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    mw, mh = W // 8, H // 8
+    # ---- input: this rank's stripe of the (virtual) W x (H*world) image -------------------
+    if world == 1:
+        data = synth_jpeg(W, H)
+        rc, frame, scan = K.host_parse(data)
+        assert rc == K.DECODE_DONE, rc
+        first_row, rows = 0, mh
+    else:
+        # restart interval = one MCU row; the stripe is generated directly (restart intervals are
+        # independent), parsed with the DRI extension, decoded as rows [rank*mh, (rank+1)*mh)
+        data = synth_jpeg(W, H, y0=rank * H, restart_interval=mw)
+        rc, frame, scan = K.host_parse(data, allow_dri=True)
+        assert rc == K.DECODE_DONE, rc
+        frame.height = H * world
+        first_row, rows = rank * mh, mh
+
+    ctx = K.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
+    d_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    d_coef = torch.empty(mw * mh * 192, dtype=torch.int16, device="cuda") if args.idct_only else None
+    torch.cuda.synchronize()
+
+    def step():
+        if args.idct_only:
+            ctx.idct_colour_dev(frame1, d_coef.data_ptr(), d_rgb.data_ptr())
+        else:
+            ctx.decode_stripe_dev(frame, d_scan.data_ptr(), d_scan.numel(), first_row, rows, d_rgb.data_ptr())
+
+    frame1 = None
+    if args.idct_only:
+        assert world == 1, "--idct-only is a single-GPU mode"
+        frame1 = frame
+        ctx.entropy_decode_dev(frame, d_scan.data_ptr(), d_scan.numel(), d_coef.data_ptr())
+        ctx.sync()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.sync()  # deferred device status of the last step (raises on a corrupt stream)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations (HIP events on the launch stream), separate pass ---------------
+    ctx.set_profiling(True)
+    acc = {}
+    nprof = max(5, min(args.steps, 20))
+    for _ in range(nprof):
+        step()
+        ctx.sync()
+        for k, v in ctx.timings().items():
+            acc[k] = acc.get(k, 0.0) + v
+    ctx.set_profiling(False)
+    tm = {k: v / nprof for k, v in acc.items()}
+
+    # ---- gather of the stripes to rank 0 (the path's one exchange step), timed apart ----------
+    gather = None
+    if world > 1 and not args.no_gather:
+        glist = [torch.empty_like(d_rgb) for _ in range(world)] if rank == 0 else None
+        for _ in range(2):
+            dist.gather(d_rgb, glist, dst=0)
+        barrier()
+        g0 = time.perf_counter()
+        nrep = 5
+        for _ in range(nrep):
+            dist.gather(d_rgb, glist, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gms = (time.perf_counter() - g0) / nrep * 1e3
+        t = torch.tensor([gms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gms = float(t.item())
+        gbytes = (world - 1) * d_rgb.numel()
+        gather = {"ms": round(gms, 4), "GB/s_into_root": round(gbytes / gms / 1e6, 2), "bytes": gbytes,
+                  "collective": "torch.distributed.gather over RCCL (grouped send/recv), RGB stripes -> rank 0"}
+
+    if rank == 0:
+        pixels_per_step = W * H * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = pixels_per_step / (ms_per_step * 1e-3) / 1e6
+        idct_ms = tm.get("idct_ms", 0.0)
+        alg_bytes = 9.0 * W * H  # per launch: this rank's stripe
+        roof = {"bound": "hbm", "achieved": round(alg_bytes / (idct_ms * 1e-3) / 1e9, 2) if idct_ms > 0 else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (idct_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if idct_ms > 0 else None,
+                "traffic": None, "kernel": "k_idct_colour_fast", "kernel_ms": round(idct_ms, 5),
+                "algorithmic_bytes": int(alg_bytes)}
+        out = {
+            "metric": "Mpixels/s decoded (JFIF->RGB) + achieved HBM GB/s, 8K 4:4:4 baseline",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("K4 only, " if args.idct_only else "") +
+                       "%dx%d 4:4:4 baseline JPEG q%d, seed %d, %s" % (
+                           W, H * world, QUALITY, SEED,
+                           "no restart markers, full on-device Huffman + IDCT" if world == 1 else
+                           "restart interval = 1 MCU row, %d row stripes of %d rows, one per GPU" % (world, H)),
+                       "scan_bytes_per_gpu": int(d_scan.numel()), "pixels_per_step": pixels_per_step},
+            "roofline": roof,
+            "kernels_ms": {k: round(v, 5) for k, v in tm.items() if k.endswith("_ms")},
+            "sync_passes": tm.get("sync_rounds"), "exact_pixels_per_image": tm.get("exact_pixels"),
+        }
+        if gather:
+            out["gather"] = gather
+            out["value_incl_gather"] = round(pixels_per_step / ((ms_per_step + gather["ms"]) * 1e-3) / 1e6, 2)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+// include/kpeg/Decoder.hpp -- kpeg::JPEGDecoder, the public decode API.
+//
+// Same public surface and result codes as the reference's include/Decoder.hpp:26-96:
+// open / close / decodeImageFile / parseSegmentInfo / dumpRawData / printCurrPos.  The marker
+// parser runs on the host and accepts/rejects exactly what the reference does;
+// at the seam where the reference calls decodeScanData() + createImageFromMCUs()
+// (src/Decoder.cpp:135-139) this class calls the C ABI of the MI355X path
+// (include/kpeg_hip.h: kpeg_hip_decode_scan).  There is no CPU decode path: without a gfx950
+// device decodeImageFile() logs an error and returns ResultCode::ERROR.
+#ifndef KPEG_DECODER_HPP
+#define KPEG_DECODER_HPP
+
+#include <iostream>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "HuffmanTree.hpp"
+#include "Image.hpp"
+#include "MCU.hpp"
+#include "Types.hpp"
+
+struct kpeg_frame;
+
+namespace kpeg
+{
+    class JPEGDecoder
+    {
+        public:
+            enum ResultCode
+            {
+                SUCCESS ,
+                TERMINATE ,
+                ERROR ,
+                DECODE_INCOMPLETE ,
+                DECODE_DONE
+            };
+
+        public:
+            ResultCode decodeImageFile();
+
+        public:
+            JPEGDecoder();
+            /// The argument is ignored, as in the reference (src/Decoder.cpp:18-22).
+            JPEGDecoder( const std::string& filename );
+            ~JPEGDecoder();
+
+            bool open( const std::string& filename );
+            void close();
+            ResultCode parseSegmentInfo( const UInt8 byte );
+            bool dumpRawData();
+
+            inline void printCurrPos()
+            {
+                std::cout << "Current file pos: 0x" << std::hex << m_pos << std::endl;
+            }
+
+            // ---- additions (off by default, outside the parity contract) ----
+            /// Accept DRI / RSTn (the reference rejects them).
+            void setRestartMarkerSupport( bool on ) { m_allowDRI = on; }
+            /// Parse only: stop at the seam and leave the tables for frameInfo().
+            void setParseOnly( bool on ) { m_parseOnly = on; }
+            /// Tables and geometry as handed to the GPU path; valid after decodeImageFile().
+            bool frameInfo( kpeg_frame* out ) const;
+            /// The entropy-coded segment as scanImageData collected it (still byte-stuffed).
+            const std::vector<UInt8>& scanData() const { return m_scan; }
+            Image& image() { return m_image; }
+            /// Parse an in-memory file instead of open().
+            void openMemory( const UInt8* data, std::size_t size, const std::string& name );
+
+        private:
+            void parseJFIFSegment();
+            void parseQuantizationTable();
+            ResultCode parseSOF0Segment();
+            void parseHuffmanTable();
+            void parseSOSSegment();
+            void parseDRISegment();
+            void scanImageData();
+            void parseComment();
+            ResultCode decodeScanData();
+
+            // byte cursor with std::ifstream's "failed reads leave the variable alone" semantics
+            bool readByte( UInt8& b );
+            UInt16 readBE16();
+            void skip( std::size_t n );
+
+        private:
+            std::string m_filename;
+            std::vector<UInt8> m_file;
+            std::size_t m_pos;
+            bool m_eof;
+            bool m_isOpen;
+
+            Image m_image;
+            std::vector<std::vector<UInt16>> m_QTables;
+            HuffmanTable m_huffmanTable[2][2];
+            HuffmanTree m_huffmanTree[2][2];
+            bool m_tableBroken;          // a table layout the reference would corrupt memory on
+
+            std::vector<UInt8> m_scan;   // entropy-coded segment (reference: m_scanData, as bytes)
+            int m_sosCount;
+            UInt32 m_restartInterval;
+            bool m_allowDRI, m_parseOnly;
+    };
+}
+
+#endif

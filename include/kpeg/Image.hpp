@@ -1,0 +1,66 @@
+// include/kpeg/Image.hpp -- decoded image store and PPM I/O.
+//
+// Same surface as the reference's include/Image.hpp:24-62.  The GPU path delivers packed
+// RGB8 rows; the reference's vector<vector<Pixel>> view (Int16 x 3 per pixel, 199 MB at 8K)
+// is materialised lazily on the first getPixelPtr() call, and dumpRawData() writes the PPM
+// straight from the RGB8 buffer.
+#ifndef KPEG_IMAGE_HPP
+#define KPEG_IMAGE_HPP
+
+#include <array>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "MCU.hpp"
+#include "Types.hpp"
+
+namespace kpeg
+{
+    class Image
+    {
+        public:
+            Image();
+
+            /// Tiles MCUs row-major into the pixel store and crops padding (reference
+            /// src/Image.cpp:20-86).  Kept for API compatibility; the decoder uses adoptRGB8().
+            void createImageFromMCUs( const std::vector<MCU>& MCUVector );
+
+            PixelPtr getPixelPtr();
+            FPixelPtr getFlPixelPtr();
+            const unsigned getWidth() const;
+            const unsigned getHeight() const;
+
+            /// Binary P6 with the reference's fixed comment line (src/Image.cpp:108-140).
+            const bool dumpRawData( const std::string& filename );
+            const bool readRawData( const std::string& filename );
+
+            void setImageFilename( const std::string& filename );
+            void setJPEGVersion( const std::string& version );
+            void setComment( const std::string& comment );
+            void setDimensions( const std::size_t width, const std::size_t height );
+
+            // ---- additions for the GPU path ----
+            /// Takes ownership of height*width*3 bytes, row-major R,G,B.
+            void adoptRGB8( std::vector<UInt8>&& rgb );
+            const std::vector<UInt8>& getRGB8() const;
+
+        private:
+            std::string  m_filename;
+            PixelPtr     m_pixelPtr;
+            FPixelPtr    m_flPixelPtr;
+            std::string  m_JPEGversion;
+            std::string  m_comment;
+            std::size_t  m_width;
+            std::size_t  m_height;
+            std::vector<UInt8> m_rgb8;
+    };
+
+    const std::string valueToBitString( const Int16 value );
+    const Int16 bitStringtoValue( const std::string& bitStr );
+    const Int16 getValueCategory( const Int16 value );
+}
+
+#endif

@@ -47,13 +47,13 @@ typedef struct kpeg_hip_ctx kpeg_hip_ctx;
 
 /* kpeg::HuffmanTable (include/Types.hpp:116) flattened: counts[i] codes of length i+1,
  * symbols in code order. */
-typedef struct {
+typedef struct kpeg_dht {
     uint8_t counts[16];
     uint8_t symbols[256];
 } kpeg_dht;
 
 /* What the marker parser knows when it reaches the seam. */
-typedef struct {
+typedef struct kpeg_frame {
     uint32_t width, height;     /* SOF0 dimensions (Decoder.cpp:361); multiples of 8          */
     uint16_t qt[2][64];         /* m_QTables[0], [1]: zig-zag order as stored (Decoder.cpp:278)
                                    [0] -> Y, [1] -> Cb and Cr (hard-wired, MCU.cpp:110)       */
@@ -65,7 +65,7 @@ typedef struct {
 
 /* Per-call device timings (milliseconds, HIP events on the context's stream), valid after
  * kpeg_hip_sync() when profiling is enabled.  0 for kernels that did not run. */
-typedef struct {
+typedef struct kpeg_hip_timings {
     float unstuff_ms;      /* K0: FF00 removal / restart-segment scan                        */
     float huff_sync_ms;    /* K1: self-synchronising sub-sequence decode (all rounds)        */
     float huff_scan_ms;    /*     prefix sums between K1 and K2                              */

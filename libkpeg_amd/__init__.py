@@ -177,3 +177,78 @@ class Context:
     def entropy_decode_dev(self, frame, d_scan, scan_len, d_coef):
         self._chk(self.lib.kpeg_hip_entropy_decode_dev(self._h, ctypes.byref(frame), ctypes.c_void_p(d_scan), scan_len,
                                                        ctypes.c_void_p(d_coef)))
+
+
+# ---------------------------------------------------------------------------------------------
+# C++ host library (kpeg::JPEGDecoder marker parser) through its C shim, include/kpeg_host.h
+PARSE_ALLOW_DRI = 1
+SUCCESS, TERMINATE, ERROR, DECODE_INCOMPLETE, DECODE_DONE = 0, 1, 2, 3, 4
+_host = None
+
+
+def load_host():
+    global _host
+    if _host is not None:
+        return _host
+    load_hip()  # libkpeg.so links against libkpeg_hip.so; keeps the HIP runtime load order
+    if not os.path.exists(HOST_LIB):
+        raise RuntimeError("%s is missing: run `python -m libkpeg_amd.build`" % HOST_LIB)
+    H = ctypes.CDLL(HOST_LIB)
+    H.kpeg_host_parse.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.POINTER(Frame), ctypes.c_void_p,
+                                  ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    H.kpeg_host_decode_file.argtypes = [ctypes.c_char_p, ctypes.c_uint]
+    H.kpeg_host_restart_offsets.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    H.kpeg_host_restart_offsets.restype = ctypes.c_size_t
+    _host = H
+    return H
+
+
+def host_parse(data, allow_dri=False):
+    """Run the product's marker parser on an in-memory JFIF file.
+    Returns (result_code, Frame or None, scan bytes (numpy uint8) or None)."""
+    H = load_host()
+    buf = np.frombuffer(data, np.uint8)
+    frame = Frame()
+    scan = np.empty(buf.size + 1, np.uint8)
+    n = ctypes.c_size_t(0)
+    rc = H.kpeg_host_parse(buf.ctypes.data, buf.size, PARSE_ALLOW_DRI if allow_dri else 0, ctypes.byref(frame),
+                           scan.ctypes.data, scan.size, ctypes.byref(n))
+    if rc != DECODE_DONE:
+        return rc, None, None
+    return rc, frame, scan[:n.value]
+
+
+def restart_offsets(scan):
+    """Byte offsets of the RSTn markers in a still-stuffed scan."""
+    H = load_host()
+    scan = np.ascontiguousarray(scan, np.uint8)
+    n = H.kpeg_host_restart_offsets(scan.ctypes.data, scan.size, None, 0)
+    out = np.empty(n, np.uint64)
+    H.kpeg_host_restart_offsets(scan.ctypes.data, scan.size, out.ctypes.data, n)
+    return out
+
+
+def stripe_ranges(scan, total_mcu_rows, mcus_per_row, restart_interval, nstripes):
+    """Split a DRI scan into `nstripes` row stripes on restart-interval boundaries.
+    Returns [(first_mcu_row, mcu_rows, byte_begin, byte_end)] -- byte range of each stripe's
+    intervals inside `scan` (RSTn between a stripe's own intervals included, the one that
+    separates it from the next stripe excluded)."""
+    assert restart_interval > 0 and (restart_interval % mcus_per_row == 0 or mcus_per_row % restart_interval == 0)
+    offs = restart_offsets(scan)
+    nint = (total_mcu_rows * mcus_per_row + restart_interval - 1) // restart_interval
+    assert len(offs) == nint - 1, "restart markers (%d) do not match the restart interval (%d intervals)" % (len(offs), nint)
+    rows_per = (total_mcu_rows + nstripes - 1) // nstripes
+    out = []
+    for s in range(nstripes):
+        r0 = min(s * rows_per, total_mcu_rows)
+        r1 = min(r0 + rows_per, total_mcu_rows)
+        if r1 <= r0:
+            out.append((r0, 0, 0, 0))
+            continue
+        assert (r0 * mcus_per_row) % restart_interval == 0, "stripe does not start on a restart interval"
+        i0 = (r0 * mcus_per_row) // restart_interval
+        i1 = (r1 * mcus_per_row + restart_interval - 1) // restart_interval
+        b0 = 0 if i0 == 0 else int(offs[i0 - 1]) + 2
+        b1 = len(scan) if i1 >= nint else int(offs[i1 - 1])
+        out.append((r0, r1 - r0, b0, b1))
+    return out

@@ -1,0 +1,433 @@
+// kpeg::JPEGDecoder -- host-side JFIF marker parser + the call into the GPU path.
+//
+// The parser reproduces the accept/reject behaviour of the reference's src/Decoder.cpp
+// (catalogued in SURVEY.md A.1), including the parts that look like bugs, because they
+// decide which files produce a PPM at all:
+//   * every marker must be introduced by exactly one FF; an unknown marker is "accepted"
+//     WITHOUT skipping its payload, so the next payload byte != FF ends the decode with
+//     ERROR (that is how DRI, APP1..15, SOF3.. are rejected)            (:53-75, :105-133)
+//   * APP0 ignores its length field and skips 3*Xthumb*Ythumb bytes                (:164-228)
+//   * DQT: (len-2)/65 tables, stored by blind push_back, so ids must arrive 0, 1   (:230-299)
+//   * SOF0 reads exactly three component triples; sampling != 1x1 -> TERMINATE     (:301-364)
+//   * DHT: several tables per segment, ids 0/1 only                                (:366-459)
+//   * SOS: selectors ignored, 3 bytes skipped, then the scan runs to FF D9         (:461-577)
+// The file is read into memory once; the byte cursor keeps std::ifstream's "a failed
+// extraction leaves the variable unchanged" semantics that the reference relies on.
+#include "Decoder.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "HipContext.hpp"
+#include "Logger.hpp"
+#include "Markers.hpp"
+#include "Transform.hpp"
+#include "Utility.hpp"
+
+namespace kpeg
+{
+    JPEGDecoder::JPEGDecoder() :
+        m_pos( 0 ), m_eof( false ), m_isOpen( false ), m_tableBroken( false ), m_sosCount( 0 ), m_restartInterval( 0 ),
+        m_allowDRI( false ), m_parseOnly( false )
+    {
+        LOG(Logger::Level::INFO) << "Created \'JPEGDecoder object\'." << std::endl;
+    }
+
+    JPEGDecoder::JPEGDecoder( const std::string& ) : JPEGDecoder() {}
+
+    JPEGDecoder::~JPEGDecoder()
+    {
+        close();
+        LOG(Logger::Level::INFO) << "Destroyed \'JPEGDecoder object\'." << std::endl;
+    }
+
+    bool JPEGDecoder::open( const std::string& filename )
+    {
+        std::ifstream in( filename, std::ios::in | std::ios::binary );
+        if ( !in.is_open() || !in.good() )
+        {
+            LOG(Logger::Level::ERROR) << "Unable to open image: \'" + filename + "\'" << std::endl;
+            return false;
+        }
+        in.seekg( 0, std::ios::end );
+        const std::streamoff n = in.tellg();
+        in.seekg( 0, std::ios::beg );
+        m_file.resize( n > 0 ? (std::size_t)n : 0 );
+        if ( n > 0 )
+            in.read( reinterpret_cast<char*>( m_file.data() ), n );
+        m_pos = 0;
+        m_eof = false;
+        m_isOpen = true;
+        m_filename = filename;
+        LOG(Logger::Level::INFO) << "Opened JPEG image: \'" + filename + "\'" << std::endl;
+        return true;
+    }
+
+    void JPEGDecoder::openMemory( const UInt8* data, std::size_t size, const std::string& name )
+    {
+        m_file.assign( data, data + size );
+        m_pos = 0;
+        m_eof = false;
+        m_isOpen = true;
+        m_filename = name;
+    }
+
+    void JPEGDecoder::close()
+    {
+        m_isOpen = false;
+        LOG(Logger::Level::INFO) << "Closed image file: \'" + m_filename + "\'" << std::endl;
+    }
+
+    // ---- byte cursor ---------------------------------------------------------------------
+    bool JPEGDecoder::readByte( UInt8& b )
+    {
+        if ( m_eof || m_pos >= m_file.size() )
+        {
+            m_eof = true;
+            return false;
+        }
+        b = m_file[m_pos++];
+        return true;
+    }
+
+    UInt16 JPEGDecoder::readBE16()
+    {
+        UInt8 hi = 0, lo = 0;
+        readByte( hi );
+        readByte( lo );
+        return (UInt16)( ( hi << 8 ) | lo );
+    }
+
+    void JPEGDecoder::skip( std::size_t n )
+    {
+        if ( m_eof )
+            return;
+        m_pos = ( m_pos + n > m_file.size() ) ? m_file.size() : m_pos + n;
+    }
+
+    // ---- marker dispatch -------------------------------------------------------------------
+    JPEGDecoder::ResultCode JPEGDecoder::parseSegmentInfo( const UInt8 byte )
+    {
+        if ( byte == JFIF_BYTE_0 || byte == JFIF_BYTE_FF )
+            return ERROR;
+
+        switch ( byte )
+        {
+            case JFIF_SOI:  LOG(Logger::Level::INFO) << "Found segment, Start of Image (FFD8)" << std::endl; return SUCCESS;
+            case JFIF_APP0: LOG(Logger::Level::INFO) << "Found segment, JPEG/JFIF Image Marker segment (APP0)" << std::endl; parseJFIFSegment(); return SUCCESS;
+            case JFIF_COM:  LOG(Logger::Level::INFO) << "Found segment, Comment(FFFE)" << std::endl; parseComment(); return SUCCESS;
+            case JFIF_DQT:  LOG(Logger::Level::INFO) << "Found segment, Define Quantization Table (FFDB)" << std::endl; parseQuantizationTable(); return SUCCESS;
+            case JFIF_SOF0: LOG(Logger::Level::INFO) << "Found segment, Start of Frame 0: Baseline DCT (FFC0)" << std::endl; return parseSOF0Segment();
+            case JFIF_SOF1: LOG(Logger::Level::INFO) << "Found segment, Start of Frame 1: Extended Sequential DCT (FFC1), Not supported" << std::endl; return TERMINATE;
+            case JFIF_SOF2: LOG(Logger::Level::INFO) << "Found segment, Start of Frame 2: Progressive DCT (FFC2), Not supported" << std::endl; return TERMINATE;
+            case JFIF_DHT:  LOG(Logger::Level::INFO) << "Found segment, Define Huffman Table (FFC4)" << std::endl; parseHuffmanTable(); return SUCCESS;
+            case JFIF_SOS:  LOG(Logger::Level::INFO) << "Found segment, Start of Scan (FFDA)" << std::endl; parseSOSSegment(); return SUCCESS;
+            case JFIF_DRI:
+                if ( m_allowDRI )
+                {
+                    LOG(Logger::Level::INFO) << "Found segment, Define Restart Interval (FFDD) [extension]" << std::endl;
+                    parseDRISegment();
+                }
+                return SUCCESS;  // reference: unknown marker, payload not skipped
+        }
+        return SUCCESS;
+    }
+
+    JPEGDecoder::ResultCode JPEGDecoder::decodeImageFile()
+    {
+        if ( !m_isOpen )
+        {
+            LOG(Logger::Level::ERROR) << "Unable scan image file: \'" + m_filename + "\'" << std::endl;
+            return ERROR;
+        }
+        LOG(Logger::Level::INFO) << "Started decoding process..." << std::endl;
+
+        UInt8 byte = 0;
+        ResultCode status = DECODE_DONE;
+        while ( readByte( byte ) )
+        {
+            if ( byte != JFIF_BYTE_FF )
+            {
+                LOG(Logger::Level::ERROR) << "[ FATAL ] Invalid JFIF file! Terminating..." << std::endl;
+                status = ERROR;
+                break;
+            }
+            readByte( byte );
+            const ResultCode code = parseSegmentInfo( byte );
+            if ( code == TERMINATE ) { status = TERMINATE; break; }
+            if ( code == DECODE_INCOMPLETE ) { status = DECODE_INCOMPLETE; break; }
+            // SUCCESS continues; ERROR (FF00 / FFFF where a marker is expected) is not acted upon
+            // by the reference's if/else chain either (src/Decoder.cpp:113-124)
+        }
+
+        if ( status == DECODE_DONE )
+        {
+            if ( m_parseOnly )
+                return status;
+            const ResultCode rc = decodeScanData();
+            if ( rc != SUCCESS )
+                return rc;
+            LOG(Logger::Level::INFO) << "Finished decoding process [OK]." << std::endl;
+        }
+        else if ( status == TERMINATE )
+        {
+            LOG(Logger::Level::INFO) << "Terminated decoding process [NOT-OK]." << std::endl;
+        }
+        else if ( status == DECODE_INCOMPLETE )
+        {
+            LOG(Logger::Level::INFO) << "Decoding process incomplete [NOT-OK]." << std::endl;
+        }
+        return status;
+    }
+
+    bool JPEGDecoder::dumpRawData()
+    {
+        std::size_t extPos = m_filename.find( ".jpg" );
+        if ( extPos == std::string::npos )
+            extPos = m_filename.find( ".jpeg" );
+        const std::string target = m_filename.substr( 0, extPos ) + ".ppm";
+        m_image.dumpRawData( target );
+        return true;
+    }
+
+    // ---- segments ----------------------------------------------------------------------------
+    void JPEGDecoder::parseJFIFSegment()
+    {
+        UInt8 b = 0, xThumb = 0, yThumb = 0, major = 0, minor = 0;
+        (void)readBE16();  // length: read, never used to skip
+        skip( 5 );         // "JFIF\0"
+        readByte( major );
+        readByte( minor );
+        m_image.setJPEGVersion( std::to_string( major ) + "." + std::to_string( minor >> 4 ) + std::to_string( minor & 0x0F ) );
+        readByte( b );     // density unit
+        (void)readBE16();  // x density
+        (void)readBE16();  // y density
+        readByte( xThumb );
+        readByte( yThumb );
+        skip( (std::size_t)3 * xThumb * yThumb );
+    }
+
+    void JPEGDecoder::parseComment()
+    {
+        const UInt16 len = readBE16();
+        std::string comment;
+        UInt8 b = 0;
+        for ( int i = 0; i < (int)len - 2; ++i )
+        {
+            readByte( b );
+            if ( b == JFIF_BYTE_FF )
+            {
+                LOG(Logger::Level::ERROR) << "Unexpected start of marker at offest: " << m_pos << std::endl;
+                return;  // gives up mid-segment without storing the comment
+            }
+            comment.push_back( (char)b );
+        }
+        m_image.setComment( comment );
+    }
+
+    void JPEGDecoder::parseQuantizationTable()
+    {
+        UInt16 len = readBE16();
+        len = (UInt16)( len - 2 );
+        for ( int t = 0; t < (int)len / 65; ++t )
+        {
+            UInt8 pqtq = 0, q = 0;
+            readByte( pqtq );
+            const std::size_t id = pqtq & 0x0F;
+            m_QTables.push_back( {} );
+            if ( id >= m_QTables.size() )
+            {
+                // the reference indexes past the vector here (undefined behaviour)
+                LOG(Logger::Level::ERROR) << "Quantization table id " << id << " before table " << m_QTables.size() - 1
+                                          << ": outside the supported layout" << std::endl;
+                m_tableBroken = true;
+                for ( int i = 0; i < 64; ++i ) readByte( q );
+                continue;
+            }
+            for ( int i = 0; i < 64; ++i )
+            {
+                readByte( q );
+                m_QTables[id].push_back( (UInt16)q );
+            }
+        }
+    }
+
+    JPEGDecoder::ResultCode JPEGDecoder::parseSOF0Segment()
+    {
+        UInt8 b = 0, id = 0, samp = 0, tq = 0;
+        (void)readBE16();
+        readByte( b );  // precision
+        const UInt16 h = readBE16();
+        const UInt16 w = readBE16();
+        readByte( b );  // component count (the loop below always reads three triples)
+        bool nonSampled = true;
+        for ( int i = 0; i < 3; ++i )
+        {
+            readByte( id );
+            readByte( samp );
+            readByte( tq );
+            if ( ( samp >> 4 ) != 1 || ( samp & 0x0F ) != 1 )
+                nonSampled = false;
+        }
+        if ( !nonSampled )
+        {
+            LOG(Logger::Level::INFO) << "Chroma subsampling not yet supported!" << std::endl;
+            return TERMINATE;
+        }
+        m_image.setDimensions( w, h );
+        return SUCCESS;
+    }
+
+    void JPEGDecoder::parseHuffmanTable()
+    {
+        const UInt16 len = readBE16();
+        const std::size_t segmentEnd = m_pos + len - 2;
+        while ( !m_eof && m_pos < segmentEnd )
+        {
+            UInt8 info = 0, c = 0;
+            readByte( info );
+            const int cls = ( info & 0x10 ) >> 4, id = info & 0x0F;
+            if ( id > 1 )
+            {
+                LOG(Logger::Level::ERROR) << "Huffman table id " << id << " is outside the supported layout" << std::endl;
+                m_tableBroken = true;
+                return;
+            }
+            HuffmanTable& t = m_huffmanTable[cls][id];
+            int total = 0;
+            for ( int i = 0; i < 16; ++i )
+            {
+                readByte( c );
+                t[i].first = c;
+                total += c;
+            }
+            // symbols are handed to the code lengths in order
+            int li = 0;
+            for ( int s = 0; s < total; ++s )
+            {
+                readByte( c );
+                while ( li < 16 && (int)t[li].second.size() >= t[li].first )
+                    ++li;
+                if ( li == 16 )
+                {
+                    m_tableBroken = true;  // redefinition of a table: the reference keeps appending
+                    break;
+                }
+                t[li].second.push_back( c );
+            }
+            m_huffmanTree[cls][id].constructHuffmanTree( t );
+        }
+    }
+
+    void JPEGDecoder::parseDRISegment()
+    {
+        (void)readBE16();
+        m_restartInterval = readBE16();
+    }
+
+    void JPEGDecoder::parseSOSSegment()
+    {
+        UInt8 n = 0, b = 0;
+        (void)readBE16();
+        readByte( n );
+        if ( n < 1 || n > 4 )
+        {
+            LOG(Logger::Level::ERROR) << "Invalid component count in image scan: " << (int)n << ", terminating decoding process..." << std::endl;
+            return;
+        }
+        for ( int i = 0; i < n; ++i )
+            (void)readBE16();  // component id + table selectors: ignored (tables are hard-wired)
+        for ( int i = 0; i < 3; ++i )
+            readByte( b );
+        m_sosCount++;
+        scanImageData();
+    }
+
+    // everything up to FF D9; an FF followed by anything else keeps both bytes
+    void JPEGDecoder::scanImageData()
+    {
+        UInt8 b = 0;
+        m_scan.reserve( m_scan.size() + ( m_file.size() - m_pos ) );
+        while ( readByte( b ) )
+        {
+            if ( b == JFIF_BYTE_FF )
+            {
+                const UInt8 prev = b;
+                readByte( b );  // at end of file b stays FF
+                if ( b == JFIF_EOI )
+                {
+                    LOG(Logger::Level::INFO) << "Found segment, End of Image (FFD9)" << std::endl;
+                    return;
+                }
+                m_scan.push_back( prev );
+            }
+            m_scan.push_back( b );
+        }
+    }
+
+    // ---- the seam ------------------------------------------------------------------------------
+    bool JPEGDecoder::frameInfo( kpeg_frame* f ) const
+    {
+        if ( !f || m_tableBroken || m_QTables.size() < 2 || m_QTables[0].size() < 64 || m_QTables[1].size() < 64 )
+            return false;
+        std::memset( f, 0, sizeof( *f ) );
+        f->width = m_image.getWidth();
+        f->height = m_image.getHeight();
+        for ( int t = 0; t < 2; ++t )
+            for ( int k = 0; k < 64; ++k )
+                f->qt[t][k] = m_QTables[t][k];  // first 64 entries: what MCU.cpp:110-112 reads
+        for ( int cls = 0; cls < 2; ++cls )
+            for ( int id = 0; id < 2; ++id )
+            {
+                int k = 0;
+                for ( int i = 0; i < 16; ++i )
+                {
+                    const auto& e = m_huffmanTable[cls][id][i];
+                    if ( e.first < 0 || e.first > 255 || (int)e.second.size() != e.first || k + e.first > 256 )
+                        return false;
+                    f->dht[cls][id].counts[i] = (UInt8)e.first;
+                    for ( UInt8 s : e.second )
+                        f->dht[cls][id].symbols[k++] = s;
+                }
+                if ( k == 0 )
+                    return false;
+            }
+        f->restart_interval = m_restartInterval;
+        return true;
+    }
+
+    JPEGDecoder::ResultCode JPEGDecoder::decodeScanData()
+    {
+        if ( m_scan.empty() )
+        {
+            LOG(Logger::Level::ERROR) << " [ FATAL ] Invalid image scan data" << std::endl;
+            return SUCCESS;  // the reference logs and still reports DECODE_DONE with an empty image
+        }
+        kpeg_frame f;
+        const unsigned w = m_image.getWidth(), h = m_image.getHeight();
+        if ( m_sosCount != 1 || !frameInfo( &f ) || w == 0 || h == 0 || ( w & 7 ) || ( h & 7 ) )
+        {
+            LOG(Logger::Level::ERROR) << "[ FATAL ] Stream is outside what libKPEG decodes without undefined behaviour "
+                                         "(two quantisation tables id 0,1; four Huffman tables id 0/1; one scan; "
+                                         "dimensions multiples of 8)" << std::endl;
+            return ERROR;
+        }
+        std::string why;
+        kpeg_hip_ctx* ctx = hip::context( &why );
+        if ( !ctx )
+        {
+            LOG(Logger::Level::ERROR) << "[ FATAL ] " << why << std::endl;
+            return ERROR;
+        }
+        std::vector<UInt8> rgb( (std::size_t)w * h * 3 );
+        const int rc = kpeg_hip_decode_scan( ctx, &f, m_scan.data(), m_scan.size(), rgb.data() );
+        if ( rc != KPEG_HIP_OK )
+        {
+            LOG(Logger::Level::ERROR) << "[ FATAL ] GPU decode failed: " << kpeg_hip_strerror( rc ) << ": " << kpeg_hip_last_error( ctx ) << std::endl;
+            return ERROR;
+        }
+        m_image.adoptRGB8( std::move( rgb ) );
+        return SUCCESS;
+    }
+}

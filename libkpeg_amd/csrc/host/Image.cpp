@@ -1,0 +1,196 @@
+// kpeg::Image -- pixel store, MCU tiling and PPM I/O (surface of the reference's src/Image.cpp).
+#include "Image.hpp"
+
+#include <cstdio>
+#include <cstring>
+
+#include "Logger.hpp"
+
+namespace kpeg
+{
+    Image::Image() :
+        m_filename{ "" }, m_pixelPtr{ nullptr }, m_flPixelPtr{ nullptr }, m_JPEGversion{ "" }, m_comment{ "" },
+        m_width{ 0 }, m_height{ 0 }
+    {
+    }
+
+    // MCU n -> tile (n / tilesPerRow, n % tilesPerRow); pixel (8*tr + v, 8*tc + u) = block[.][v][u];
+    // columns/rows beyond the image size are cropped (reference src/Image.cpp:26-84).
+    void Image::createImageFromMCUs( const std::vector<MCU>& MCUVector )
+    {
+        const std::size_t tw = ( m_width + 7 ) / 8, th = ( m_height + 7 ) / 8;
+        if ( MCUVector.size() < tw * th )
+        {
+            LOG(Logger::Level::ERROR) << "createImageFromMCUs: " << MCUVector.size() << " MCUs given, " << tw * th << " needed" << std::endl;
+            return;
+        }
+        std::vector<UInt8> rgb( m_width * m_height * 3 );
+        for ( std::size_t tr = 0; tr < th; ++tr )
+            for ( std::size_t tc = 0; tc < tw; ++tc )
+            {
+                const CompMatrices& b = MCUVector[tr * tw + tc].getAllMatrices();
+                for ( std::size_t v = 0; v < 8 && tr * 8 + v < m_height; ++v )
+                    for ( std::size_t u = 0; u < 8 && tc * 8 + u < m_width; ++u )
+                        for ( int c = 0; c < 3; ++c )
+                            rgb[( ( tr * 8 + v ) * m_width + tc * 8 + u ) * 3 + c] = (UInt8)b[c][v][u];
+            }
+        adoptRGB8( std::move( rgb ) );
+    }
+
+    void Image::adoptRGB8( std::vector<UInt8>&& rgb )
+    {
+        m_rgb8 = std::move( rgb );
+        m_pixelPtr.reset();
+    }
+
+    const std::vector<UInt8>& Image::getRGB8() const { return m_rgb8; }
+
+    PixelPtr Image::getPixelPtr()
+    {
+        if ( !m_pixelPtr && m_rgb8.size() == m_width * m_height * 3 && !m_rgb8.empty() )
+        {
+            m_pixelPtr = std::make_shared<std::vector<std::vector<Pixel>>>( m_height, std::vector<Pixel>( m_width ) );
+            const UInt8* p = m_rgb8.data();
+            for ( auto& row : *m_pixelPtr )
+                for ( auto& px : row )
+                {
+                    px.comp[0] = p[0];
+                    px.comp[1] = p[1];
+                    px.comp[2] = p[2];
+                    p += 3;
+                }
+        }
+        return m_pixelPtr;
+    }
+
+    FPixelPtr Image::getFlPixelPtr() { return m_flPixelPtr; }
+    const unsigned Image::getWidth() const { return (unsigned)m_width; }
+    const unsigned Image::getHeight() const { return (unsigned)m_height; }
+
+    const bool Image::dumpRawData( const std::string& filename )
+    {
+        const bool haveRGB = !m_rgb8.empty() && m_rgb8.size() == m_width * m_height * 3;
+        if ( !haveRGB && m_pixelPtr == nullptr )
+        {
+            LOG(Logger::Level::ERROR) << "Unable to create dump file \'" + filename + "\', Invalid pixel pointer" << std::endl;
+            return false;
+        }
+        std::FILE* f = std::fopen( filename.c_str(), "wb" );
+        if ( !f )
+        {
+            LOG(Logger::Level::ERROR) << "Unable to create dump file \'" + filename + "\'." << std::endl;
+            return false;
+        }
+        // header bytes are part of the bit-exact output (reference src/Image.cpp:124-127)
+        std::fprintf( f, "P6\n# PPM dump created using libKPEG: https://github.com/TheIllusionistMirage/libKPEG\n%zu %zu\n255\n",
+                      m_width, m_height );
+        bool ok = true;
+        if ( haveRGB )
+            ok = std::fwrite( m_rgb8.data(), 1, m_rgb8.size(), f ) == m_rgb8.size();
+        else
+            for ( auto&& row : *m_pixelPtr )
+                for ( auto&& px : row )
+                {
+                    const UInt8 b[3] = { (UInt8)px.comp[0], (UInt8)px.comp[1], (UInt8)px.comp[2] };
+                    ok = ok && std::fwrite( b, 1, 3, f ) == 3;
+                }
+        ok = ( std::fclose( f ) == 0 ) && ok;
+        if ( ok )
+        {
+            LOG(Logger::Level::INFO) << "Raw image data dumped to file: \'" + filename + "\'." << std::endl;
+        }
+        return ok;
+    }
+
+    // Binary P6 reader (used by the reference's encoder only; kept for API completeness).
+    const bool Image::readRawData( const std::string& filename )
+    {
+        std::ifstream in( filename, std::ios::in | std::ios::binary );
+        if ( !in.is_open() || !in.good() )
+        {
+            LOG(Logger::Level::ERROR) << "Unable to read PPM file: \'" + filename + "\'" << std::endl;
+            return false;
+        }
+        char magic[2] = { 0, 0 };
+        in.read( magic, 2 );
+        if ( magic[0] != 'P' || magic[1] != '6' )
+        {
+            LOG(Logger::Level::ERROR) << "Invalid PPM file: \'" + filename + "\'" << std::endl;
+            return false;
+        }
+        auto skipCommentsAndSpace = [&in]() {
+            for ( ;; )
+            {
+                int c = in.peek();
+                if ( c == '#' ) { std::string line; std::getline( in, line ); }
+                else if ( c == ' ' || c == '\n' || c == '\r' || c == '\t' ) in.get();
+                else break;
+            }
+        };
+        unsigned width = 0, height = 0, maxv = 0;
+        skipCommentsAndSpace(); in >> width;
+        skipCommentsAndSpace(); in >> height;
+        skipCommentsAndSpace(); in >> maxv;
+        in.get();  // single whitespace before the raster
+        if ( !in.good() || width == 0 || height == 0 )
+            return false;
+        m_width = width;
+        m_height = height;
+        m_flPixelPtr = std::make_shared<std::vector<std::vector<FPixel>>>( height, std::vector<FPixel>( width ) );
+        std::vector<UInt8> row( (std::size_t)width * 3 );
+        for ( unsigned y = 0; y < height; ++y )
+        {
+            in.read( reinterpret_cast<char*>( row.data() ), row.size() );
+            if ( (std::size_t)in.gcount() != row.size() )
+                return false;
+            for ( unsigned x = 0; x < width; ++x )
+                ( *m_flPixelPtr )[y][x] = FPixel( row[x * 3], row[x * 3 + 1], row[x * 3 + 2] );
+        }
+        m_filename = filename;
+        return true;
+    }
+
+    void Image::setImageFilename( const std::string& filename ) { m_filename = filename; }
+    void Image::setJPEGVersion( const std::string& version ) { m_JPEGversion = version; }
+    void Image::setComment( const std::string& comment ) { m_comment = comment; }
+    void Image::setDimensions( const std::size_t width, const std::size_t height )
+    {
+        m_width = width;
+        m_height = height;
+    }
+
+    // ---- bit-string helpers (reference src/Image.cpp:258-320) ------------------------------
+    const Int16 getValueCategory( const Int16 value )
+    {
+        int a = value < 0 ? -(int)value : (int)value, cat = 0;
+        while ( a ) { ++cat; a >>= 1; }
+        return (Int16)cat;
+    }
+
+    // magnitude bits of a coefficient: the value itself if positive, its one's complement if negative
+    const std::string valueToBitString( const Int16 value )
+    {
+        if ( value == 0 )
+            return "";
+        const int cat = getValueCategory( value );
+        const int bits = value > 0 ? value : ( ( 1 << cat ) - 1 ) + value;
+        std::string s( cat, '0' );
+        for ( int i = 0; i < cat; ++i )
+            if ( bits & ( 1 << ( cat - 1 - i ) ) )
+                s[i] = '1';
+        return s;
+    }
+
+    // JPEG EXTEND: leading '1' -> +binary value, leading '0' -> -(one's complement), "" -> 0
+    const Int16 bitStringtoValue( const std::string& bitStr )
+    {
+        if ( bitStr.empty() )
+            return 0;
+        int v = 0;
+        for ( char ch : bitStr )
+            v = ( v << 1 ) | ( ch == '1' ? 1 : 0 );
+        if ( bitStr[0] == '1' )
+            return (Int16)v;
+        return (Int16)( -( ( ( 1 << bitStr.size() ) - 1 ) - v ) );
+    }
+}

@@ -1,0 +1,84 @@
+// kpeg -- command line front end: `kpeg <file.jpg>` writes <file>.ppm.
+//
+// Same contract as the reference's main.cpp:19-79 for the decode direction: the file name
+// must end in ".jpg" (isValidFilename), the PPM lands next to the input, kpeg.log is created
+// in the working directory.  The encode direction (`kpeg in.ppm out.jpg`) belongs to the
+// reference's unfinished encoder and is out of scope here; it reports that and exits.
+// Extension: `--allow-dri` accepts streams with restart markers.
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "Decoder.hpp"
+#include "Logger.hpp"
+#include "Utility.hpp"
+
+static void printHelp()
+{
+    std::cout << "===========================================" << std::endl;
+    std::cout << "   K-PEG - Simple JPEG Decoder (MI355X)"      << std::endl;
+    std::cout << "===========================================" << std::endl;
+    std::cout << "Help\n" << std::endl;
+    std::cout << "<filename.jpg>                  : Decompress a JPEG image to a PPM image" << std::endl;
+    std::cout << "--allow-dri <filename.jpg>      : same, accepting restart markers (extension)" << std::endl;
+    std::cout << "-h                              : Print this help message and exit" << std::endl;
+}
+
+static int decodeJPEG( const std::string& filename, bool allowDRI )
+{
+    if ( !kpeg::isValidFilename( filename ) )
+    {
+        LOG(kpeg::Logger::Level::ERROR) << "Invalid input file name passed." << std::endl;
+        return EXIT_SUCCESS;  // the reference returns success here too (main.cpp:21-25,73)
+    }
+    kpeg::JPEGDecoder decoder;
+    decoder.setRestartMarkerSupport( allowDRI );
+    decoder.open( filename );
+    if ( decoder.decodeImageFile() == kpeg::JPEGDecoder::ResultCode::DECODE_DONE )
+        decoder.dumpRawData();
+    return EXIT_SUCCESS;
+}
+
+int main( int argc, char** argv )
+{
+    try
+    {
+        std::ofstream logFile( "kpeg.log", std::ios::out );
+        kpeg::TeeStream logTee( logFile, std::cout );
+        if ( logFile.is_open() && logFile.good() )
+            kpeg::Logger::get().setLogStream( logTee );
+        else
+            kpeg::Logger::get().setLogStream( std::cout );
+        kpeg::Logger::get().setLevel( kpeg::Logger::Level::DEBUG );
+        LOG(kpeg::Logger::Level::INFO) << "KPEG - Simple JPEG Decoder (MI355X path)" << std::endl;
+
+        if ( argc < 2 )
+        {
+            LOG(kpeg::Logger::Level::ERROR) << "No arguments provided." << std::endl;
+            return EXIT_FAILURE;
+        }
+        if ( argc == 2 && std::string( argv[1] ) == "-h" )
+        {
+            printHelp();
+            return EXIT_SUCCESS;
+        }
+        if ( argc == 2 )
+            return decodeJPEG( argv[1], false );
+        if ( argc == 3 && std::string( argv[1] ) == "--allow-dri" )
+            return decodeJPEG( argv[2], true );
+        if ( argc == 3 )
+        {
+            LOG(kpeg::Logger::Level::ERROR) << "The PPM->JPEG encoder of libKPEG is unfinished upstream and is not part of this build." << std::endl;
+            return EXIT_SUCCESS;
+        }
+        return EXIT_FAILURE;
+    }
+    catch ( std::exception& e )
+    {
+        std::cout << "Exceptions Occurred:-" << std::endl;
+        std::cout << "What: " << e.what() << std::endl;
+    }
+    return EXIT_SUCCESS;
+}

@@ -219,6 +219,9 @@ def synth():
         S.kpeg_synth_jpeg.restype = ctypes.c_size_t
         S.kpeg_synth_jpeg.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32,
                                       ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+        S.kpeg_synth_jpeg_rows.restype = ctypes.c_size_t
+        S.kpeg_synth_jpeg_rows.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int,
+                                           ctypes.c_uint32, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
         S.kpeg_synth_encode_rgb.restype = ctypes.c_size_t
         S.kpeg_synth_encode_rgb.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32,
                                             ctypes.c_void_p, ctypes.c_size_t]
@@ -229,11 +232,12 @@ def synth():
     return _synth
 
 
-def synth_jpeg(w, h, seed=1234, quality=75, restart_interval=0, sigma=6.0, mode=0):
-    """SURVEY.md 8(d) synthetic 4:4:4 baseline JPEG (mode 1 = dense uniform noise)."""
+def synth_jpeg(w, h, seed=1234, quality=75, restart_interval=0, sigma=6.0, mode=0, y0=0):
+    """SURVEY.md 8(d) synthetic 4:4:4 baseline JPEG (mode 1 = dense uniform noise).
+    y0: first row of the (virtual) full image this file covers."""
     cap = w * h * 3 + (w * h) // 2 + 65536
     buf = np.empty(cap, np.uint8)
-    n = synth().kpeg_synth_jpeg(w, h, seed, quality, restart_interval, sigma, mode, buf.ctypes.data, cap)
+    n = synth().kpeg_synth_jpeg_rows(w, h, y0, seed, quality, restart_interval, sigma, mode, buf.ctypes.data, cap)
     assert n > 0, "synthetic encoder overflow"
     return buf[:n].tobytes()
 

@@ -461,8 +461,20 @@ size_t kpeg_synth_encode_rgb(const uint8_t* rgb, uint32_t w, uint32_t h, int qua
 /* The SURVEY.md 8(d) synthetic image, generated one MCU row at a time so that a
  * 16384x16384 input never needs its 805 MB RGB source in memory.
  * mode 0: smooth field + N(0,sigma) noise; mode 1: uniform noise. */
+size_t kpeg_synth_jpeg_rows(uint32_t w, uint32_t h, uint32_t y0, uint64_t seed, int quality, uint32_t restart_interval,
+                            double sigma, int mode, uint8_t* out, size_t cap);
+
 size_t kpeg_synth_jpeg(uint32_t w, uint32_t h, uint64_t seed, int quality, uint32_t restart_interval, double sigma,
                        int mode, uint8_t* out, size_t cap)
+{
+    return kpeg_synth_jpeg_rows(w, h, 0, seed, quality, restart_interval, sigma, mode, out, cap);
+}
+
+/* Same image function, but the h rows start at row y0 of the (virtual) full image: with a
+ * restart interval of whole MCU rows the result is byte-for-byte the stripe of the full
+ * image's entropy data (restart intervals are independent), apart from the RSTn numbering. */
+size_t kpeg_synth_jpeg_rows(uint32_t w, uint32_t h, uint32_t y0, uint64_t seed, int quality, uint32_t restart_interval,
+                            double sigma, int mode, uint8_t* out, size_t cap)
 {
     if ((w & 7) || (h & 7) || !w || !h) return 0;
     init_dct();
@@ -475,7 +487,7 @@ size_t kpeg_synth_jpeg(uint32_t w, uint32_t h, uint64_t seed, int quality, uint3
         uint8_t* rows = (uint8_t*)malloc((size_t)8 * w * 3);
 #pragma omp for schedule(static)
         for (long tr = 0; tr < (long)mh; ++tr) {
-            for (int r = 0; r < 8; ++r) field_row(w, (uint32_t)tr * 8 + r, seed, sigma, mode, rows + (size_t)r * w * 3);
+            for (int r = 0; r < 8; ++r) field_row(w, y0 + (uint32_t)tr * 8 + r, seed, sigma, mode, rows + (size_t)r * w * 3);
             mcu_row_coefs(rows, w, ql, qc, coef + (size_t)tr * mw * 192);
         }
         free(rows);
