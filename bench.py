@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--height", type=int, default=H8K, help="rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--idct-mode", type=int, default=0, help="kpeg_hip_set_idct_mode (2 = timing experiment, wrong pixels)")
     ap.add_argument("--idct-only", action="store_true", help="time K4 alone on resident coefficients (BASELINE config 2 style)")
     args = ap.parse_args()
 
@@ -149,6 +150,7 @@ def main():
     ctx = K.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_idct_mode(args.idct_mode)
     d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
     d_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
     d_coef = torch.empty(mw * mh * 192, dtype=torch.int16, device="cuda") if args.idct_only else None

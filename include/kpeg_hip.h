@@ -132,7 +132,8 @@ int kpeg_hip_entropy_decode_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, cons
 
 /* ---- knobs for tests and benchmarks ------------------------------------------------------- */
 /* IDCT kernel variant: 0 = fast path with exact re-evaluation of unsafe samples (default),
- * 1 = reference-order evaluation of every sample (slow, used as an on-device cross-check). */
+ * 1 = reference-order evaluation of every sample (slow, used as an on-device cross-check),
+ * 2 = fast path WITHOUT the re-evaluation: wrong pixels, timing experiments only. */
 int kpeg_hip_set_idct_mode(kpeg_hip_ctx* ctx, int mode);
 
 #ifdef __cplusplus

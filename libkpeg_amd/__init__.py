@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, "libkpeg_hip.so")
+HIP_LIB = os.environ.get("KPEG_HIP_LIB") or os.path.join(_HERE, "libkpeg_hip.so")  # override: kernel experiments only
 HOST_LIB = os.path.join(_HERE, "libkpeg.so")
 CLI = os.path.join(_HERE, "kpeg")
 

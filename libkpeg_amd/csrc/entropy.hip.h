@@ -46,12 +46,23 @@ struct EntropyTables {  // built on the host per frame, copied to the device whe
     int32_t valoff[4][18];           // symbol index of the first code of each length minus that code
     uint8_t symbols[4][256];
     uint8_t zz[64];                  // zig-zag -> natural
+    float mscale[2][64];             // 0.25 * cc[u][v] * Q[u][v], natural order ([.][0] unused): K4's input scale
+    float q00[2];                    // Q[0][0] of both tables
 };
 
 static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
 {
     std::memset(t, 0, sizeof(*t));
     for (int k = 0; k < 64; ++k) t->zz[k] = KPEG_ZZ_TO_NATURAL[k];
+    for (int tq = 0; tq < 2; ++tq) {
+        const float c0 = 0x1.6a09e6p-1f;  // (float)(1/sqrt 2), as in K4's cc_of()
+        for (int k = 0; k < 64; ++k) {
+            const int nat = KPEG_ZZ_TO_NATURAL[k], u = nat >> 3, v = nat & 7;
+            const float cc = (u == 0 ? c0 : 1.0f) * (v == 0 ? c0 : 1.0f);
+            t->mscale[tq][nat] = 0.25f * cc * (float)f->qt[tq][k];
+        }
+        t->q00[tq] = (float)f->qt[tq][0];
+    }
     for (int cls = 0; cls < 2; ++cls)
         for (int id = 0; id < 2; ++id) {
             const kpeg_dht& h = f->dht[cls][id];
@@ -116,6 +127,7 @@ struct EntropyLaunch {
     uint32_t nmcu;
     uint32_t restart_interval;
     int16_t* d_coef;
+    float* d_ebound;
     uint32_t* d_status;
     int num_cus;
     int sync_passes;   // 0 = default
@@ -346,6 +358,8 @@ struct LdsTables {
     int32_t valoff[4][18];
     uint8_t symbols[4][256];
     uint8_t zz[64];
+    float mscale[2][64];
+    float q00[2];
 };
 
 __device__ __forceinline__ void load_tables(LdsTables* dst, const EntropyTables* src)
@@ -673,6 +687,7 @@ struct WriteArgs {
     const int4* wsum;    // exclusive prefix of the per-workgroup totals
     const int4* prefix;  // materialised exclusive prefix (restart segments only, else null)
     int16_t* coef;
+    float* ebound;       // [block] K4's per-block error bound
     uint32_t nsub_cap;
     uint32_t nmcu;
     uint32_t interval;   // 0 = none
@@ -780,6 +795,9 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         const bool keep_ac = sym != 0;  // quirk Q1: a DC "EOB" drops the block's AC terms (MCU.cpp:97-100)
         uint32_t k = 1;                 // coefficients placed so far + 1
         uint64_t touched = 0;
+        // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
+        float Asum = fabsf(0.25f * (0x1.fffffep-2f * ((float)pred[c] * T.q00[tdc])));
+        int nnz = 0;
         while (k < 64) {
             win = peek32(w, s.p);
             if (!decode_symbol(T, win, tac, sym, len)) err |= 8;
@@ -798,8 +816,11 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
             }
             if (keep_ac) {
                 const int nat = T.zz[k - 1];
-                blk[nat] = (int16_t)extend(bits, cat);
+                const int val = extend(bits, cat);
+                blk[nat] = (int16_t)val;
                 touched |= 1ull << nat;
+                Asum += fabsf((float)val * T.mscale[tdc][nat]);
+                nnz += val != 0;
             }
         }
         if (s.p > seg_pend + 32) err |= 64;  // ran off the end of the data
@@ -810,6 +831,7 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
             const uint4* src = reinterpret_cast<const uint4*>(blk);
 #pragma unroll
             for (int q = 0; q < 8; ++q) dst[q] = src[q];
+            a.ebound[gb] = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;  // == block_ebound()
             if (touched) {
                 uint4 z = make_uint4(0, 0, 0, 0);
                 uint4* b4 = reinterpret_cast<uint4*>(blk);
@@ -939,6 +961,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     wa.wsum = (const int4*)S->d_wsum;
     wa.prefix = rst ? prefix : nullptr;
     wa.coef = L.d_coef;
+    wa.ebound = L.d_ebound;
     wa.nsub_cap = nsub_cap;
     wa.nmcu = L.nmcu;
     wa.interval = L.restart_interval;

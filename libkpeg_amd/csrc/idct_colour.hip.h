@@ -63,13 +63,15 @@ struct QTables {
 
 struct IdctParams {
     const int16_t* coef;  // [mcu][3][8][8] quantised, natural order
+    const float* ebound;  // [mcu][3] per-block error bound E (sample units), see k_ebound
     uint8_t* rgb;         // output stripe base (row 0 = first pixel row of mcu_row0)
     uint32_t mcus_w;      // MCUs per MCU row (width / 8)
     uint32_t mcu_rows;    // MCU rows to produce
     uint32_t pitch;       // bytes per pixel row (width * 3)
-    uint32_t tiles_w;     // ceil(mcus_w / 32)
+    uint32_t tiles_w;     // ceil(mcus_w / TILE_MCUS)
     uint32_t ntiles;      // tiles_w * mcu_rows
-    uint32_t* stats;      // [0] += pixels sent to the exact path (may be null)
+    uint32_t* stats;      // [256] counters: [blockIdx & 255] += pixels sent to the exact path (may be null)
+    uint32_t skip_exact;  // timing experiments only: count unsafe pixels but do not re-evaluate them
 };
 
 // ---- reference-order arithmetic ---------------------------------
@@ -172,36 +174,61 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
 
 // ---- mode 0: fast path + exact re-evaluation ---------------------------------------------
 
-// Error-bound constants; derivation and numeric check: tools/idct_bound.py, DESIGN.md.
-//   |fast - reference float result| <= U * A * (nnz_bound + KAPPA)     (sample units)
-// with U = 2^-24 (1 + 2^-20), A = sum |in| over the block, when the block has AC terms.
-#define KPEG_KAPPA 24.0f
-#define KPEG_U 0x1.00001p-24f
-// chroma magnitude below which the f32 colour arithmetic is proven exact
+// Error bound (derivation and numeric check: tools/idct_bound.py, DESIGN.md "K4 exactness"):
+//   |fast - reference float result| <= E = U * A * (nnz_ac + KAPPA)            (sample units)
+// U = 2^-24 (1 + 2^-10), A = sum |in| over the block (in = 0.25 * cc * Q * coefficient),
+// nnz_ac = non-zero AC coefficients (one float rounding of the reference's accumulator per
+// non-zero AC term), KAPPA bounds the fast path's own roundings.  Blocks without AC terms are
+// exact (E = 0).  E is produced per block by whoever writes the coefficients (K2, or k_ebound
+// for caller-supplied coefficients) and read here as a 4-byte sidecar per block.
+#define KPEG_KAPPA 14.5f      // tools/idct_bound.py prints 14.444
+#define KPEG_U 0x1.004p-24f   // 2^-24 (1 + 2^-10): covers the f32 rounding of A's own summation
+// chroma magnitude below which the f32 colour arithmetic is proven exact (DESIGN.md "colour")
 #define KPEG_CHROMA_LIM 250.0f
-#define KPEG_LUMA_LIM 1048576.0f
+#define KPEG_LUMA_LIM 32000.0f
 // |t - rint(t)| below this sends the G channel to the exact path (f32 error of t <= 3.7e-5)
 #define KPEG_G_DELTA 6.0e-5f
 
-constexpr int TILE_MCUS = 32;                 // MCUs per workgroup iteration
-constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 768
-constexpr int TILE_ROW_STRIDE = 816;          // padded: 204 dwords = 12 mod 32 banks
-constexpr int QUEUE_CAP = TILE_MCUS * 64;     // every pixel of the tile
+__device__ __forceinline__ float block_ebound(float A, int nnz_ac)
+{
+    return nnz_ac ? (KPEG_U * A) * ((float)nnz_ac + KPEG_KAPPA) : 0.0f;
+}
 
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v)
+// E for caller-supplied coefficients (kpeg_hip_idct_colour): one thread per block.
+__global__ __launch_bounds__(256) void k_ebound(const int16_t* coef, uint32_t nblocks, QTables qt, float* ebound)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= nblocks) return;
+    const int t = (b % 3) ? 1 : 0;
+    const uint4* src = reinterpret_cast<const uint4*>(coef + (size_t)b * 64);
+    float A = 0.f;
+    int n = 0;
+    for (int r = 0; r < 8; ++r) {
+        const uint4 d = src[r];
+        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+        for (int i = 0; i < 8; ++i) {
+            const int c = (int)(short)((w[i >> 1] >> ((i & 1) * 16)) & 0xFFFF);
+            const int k = r * 8 + i;
+            if (k == 0) {
+                A += fabsf(0.25f * (cc_of(0, 0) * ((float)c * (float)qt.q[t][0])));
+            } else if (c != 0) {
+                A += fabsf((float)c * (0.25f * cc_of(r, i) * (float)qt.q[t][k]));
+                n++;
+            }
+        }
+    }
+    ebound[b] = block_ebound(A, n);
 }
-template <int CTRL>
-__device__ __forceinline__ int dppi(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
-}
-#define DPP_QUAD_BCAST(k) ((k) | ((k) << 2) | ((k) << 4) | ((k) << 6))
-#define DPP_QUAD_XOR1 0xB1   // [1,0,3,2]
-#define DPP_QUAD_XOR2 0x4E   // [2,3,0,1]
-#define DPP_HALF_MIRROR 0x141
+
+typedef unsigned int uint3v __attribute__((ext_vector_type(3)));
+constexpr int TILE_MCUS = 8;                    // MCUs per wavefront iteration (8 lane groups)
+constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 192
+constexpr int TILE_ROW_STRIDE = 208;            // padded: 13 x 16 bytes, conflict-free b64 writes across rows
+constexpr int QUEUE_CAP = TILE_MCUS * 64 * 2;   // every pixel of the tile, twice (range pass)
+#ifndef KPEG_K4_OCC
+#define KPEG_K4_OCC 6
+#endif
+constexpr int K4_WAVES_PER_CU = 4 * KPEG_K4_OCC;  // one wavefront per workgroup, KPEG_K4_OCC per SIMD
 
 // 1-D 8-point inverse DCT kernel sum_v a[v] cos((2y+1) v pi/16), y = 0..7, in place.
 __device__ __forceinline__ void row_idct8(float a[8])
@@ -228,6 +255,44 @@ __device__ __forceinline__ void row_idct8(float a[8])
     a[4] = e3 - o3;
 }
 
+// Column pass across the 8 lanes of an MCU group, all 8 pixel columns at once.
+// Lanes 0-3 hold rows 0,2,4,6 of g and produce the even sums, lanes 4-7 hold rows 1,3,5,7 and
+// produce the negated odd sums; quad_perm broadcasts feed v_fmac_f32_dpp directly (hipcc only
+// folds DPP into VOP2 multiplies, not into FMAs, hence the asm), and one row_half_mirror FMA
+// combines the two halves: out = own + mirror * s.
+// Hazard (VALU write -> DPP read of the same VGPR needs 2 wait states): the leading s_nop covers
+// the compiler-produced g; inside, every DPP read is >= 8 instructions behind its producer.
+__device__ __forceinline__ void column_idct8(const float g[8], float k0, float k1, float k2, float k3, float s, float o[8])
+{
+#define KPEG_DPP8(op, sel, kreg)                                                                    \
+    op " %0, %8, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    op " %1, %9, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    op " %2, %10, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                  \
+    op " %3, %11, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                  \
+    op " %4, %12, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                  \
+    op " %5, %13, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                  \
+    op " %6, %14, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                  \
+    op " %7, %15, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t"
+        KPEG_DPP8("v_mul_f32_dpp", "quad_perm:[0,0,0,0]", "%16")
+        KPEG_DPP8("v_fmac_f32_dpp", "quad_perm:[1,1,1,1]", "%17")
+        KPEG_DPP8("v_fmac_f32_dpp", "quad_perm:[2,2,2,2]", "%18")
+        KPEG_DPP8("v_fmac_f32_dpp", "quad_perm:[3,3,3,3]", "%19")
+        "v_fmac_f32_dpp %0, %0, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(k0), "v"(k1),
+          "v"(k2), "v"(k3), "v"(s));
+#undef KPEG_DPP8
+}
+
 __device__ __forceinline__ float cosf_tab(int k)  // cos(k*pi/16), k = 0..31, f32-rounded
 {
     const float t[9] = {1.0f,
@@ -245,234 +310,258 @@ __device__ __forceinline__ float cosf_tab(int k)  // cos(k*pi/16), k = 0..31, f3
 }
 
 struct LaneConst {
-    float m[2][8];   // AC input scale 0.25 * cc[u][v] * Q[u][v] for Y / chroma tables
     float q0[2];     // Q[u][0] as float (exact DC-column chain)
     float cc0;       // cc[u][0]
     float k[4];      // column-pass constants
     float s;         // -1 on even-row lanes, +1 on odd-row lanes
-    uint32_t dcmask; // clears the DC halfword on the lane that owns row 0
 };
 
-// One component block: loads are already in d[4] (8 int16, row u of the block).
-// Returns the 8 fast sample values of pixel row (lane & 7) in out[8] and the
-// block's unsafe threshold (0.5 - E).
-__device__ __forceinline__ float block_fast(const uint4 d, const LaneConst& lc, int tab, float out[8])
+// One component block: d = 8 int16 (row u of the block, this lane's share).
+// out[i] = fast value of sample i of pixel row (lane & 7).
+__device__ __forceinline__ void block_fast(const uint4 d, const LaneConst& lc, const float* __restrict__ m, int tab, float out[8])
 {
-    int w[4] = {(int)d.x, (int)d.y, (int)d.z, (int)d.w};
+    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
     float a[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         a[2 * i] = (float)(short)(w[i] & 0xFFFF);
-        a[2 * i + 1] = (float)(w[i] >> 16);
+        a[2 * i + 1] = (float)((int)w[i] >> 16);
     }
-    // nnz bound: sum of squares of the AC coefficients (>= number of non-zero ones),
-    // saturating, then clamped per lane so that the cross-lane sum cannot overflow
-    int n = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, (int)(w[0] & lc.dcmask)),
-                                   __builtin_bit_cast(short2v, (int)(w[0] & lc.dcmask)), 0, true);
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-        n = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, w[i]), __builtin_bit_cast(short2v, w[i]), n, true);
-    n = min(n, 63);
-    // inputs: column 0 through the reference's own chain 0.25 * (cc * (float)(c*Q)), exact for DC
-    float in0 = 0.25f * (lc.cc0 * (a[0] * lc.q0[tab]));
-    a[0] = in0;
-    float A = fabsf(in0);
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        a[i] *= lc.m[tab][i];
-        A += fabsf(a[i]);
-    }
+    // column 0 through the reference's own chain 0.25 * (cc * (float)(c*Q)): exact for the DC term
+    a[0] = 0.25f * (lc.cc0 * (a[0] * lc.q0[tab]));
+    // AC input scale 0.25 * cc[u][v] * Q[u][v] of this lane's row, from LDS (m[0] unused)
+    const float4 mlo = *reinterpret_cast<const float4*>(m), mhi = *reinterpret_cast<const float4*>(m + 4);
+    a[1] *= mlo.y;
+    a[2] *= mlo.z;
+    a[3] *= mlo.w;
+    a[4] *= mhi.x;
+    a[5] *= mhi.y;
+    a[6] *= mhi.z;
+    a[7] *= mhi.w;
     row_idct8(a);
-    // block totals over the 8 lanes of the group
-    A += dpp<DPP_HALF_MIRROR>(A);
-    A += dpp<DPP_QUAD_XOR1>(A);
-    A += dpp<DPP_QUAD_XOR2>(A);
-    n += dppi<DPP_HALF_MIRROR>(n);
-    n += dppi<DPP_QUAD_XOR1>(n);
-    n += dppi<DPP_QUAD_XOR2>(n);
-    float nb = (float)min(n, 63);
-    float E = (KPEG_U * A) * (nb + (n > 0 ? KPEG_KAPPA : 0.0f));
-    // column pass across lanes
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-        float g = a[y];
-        float acc = dpp<DPP_QUAD_BCAST(0)>(g) * lc.k[0];
-        acc = __builtin_fmaf(dpp<DPP_QUAD_BCAST(1)>(g), lc.k[1], acc);
-        acc = __builtin_fmaf(dpp<DPP_QUAD_BCAST(2)>(g), lc.k[2], acc);
-        acc = __builtin_fmaf(dpp<DPP_QUAD_BCAST(3)>(g), lc.k[3], acc);
-        out[y] = __builtin_fmaf(dpp<DPP_HALF_MIRROR>(acc), lc.s, acc);
-    }
-    return 0.5f - E;
+    column_idct8(a, lc.k[0], lc.k[1], lc.k[2], lc.k[3], lc.s, out);
 }
 
-__global__ __launch_bounds__(256) void k_idct_colour_fast(IdctParams p, QTables qt)
+__device__ __forceinline__ uint32_t pk_u8(float v, uint32_t sel, uint32_t old)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, old);  // saturating float -> byte `sel` of old
+}
+
+// One wavefront per workgroup: no workgroup barrier anywhere, every wave is an independent
+// worker walking its own tiles of 8 MCUs (64 x 8 pixels).  Small register footprint on purpose:
+// VALU issue on gfx950 needs >= 4 resident waves per SIMD to approach its rate
+// (tools/ubench/valu_rate.hip).
+__global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams p, QTables qt)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[8 * TILE_ROW_STRIDE];
-    __shared__ uint32_t s_queue[QUEUE_CAP];
-    __shared__ uint32_t s_qcount;
+    __shared__ uint2 s_queue[QUEUE_CAP];
+    __shared__ __attribute__((aligned(16))) float s_m[2][64];  // AC input scales, natural order
 
     const int tid = threadIdx.x;
     const int lane8 = tid & 7;          // lane within the MCU group = output pixel row
-    const int grp = tid >> 3;           // MCU within the tile, 0..31
+    const int grp = tid >> 3;           // MCU within the tile, 0..7
     const int u = lane8 < 4 ? 2 * lane8 : 2 * (lane8 - 4) + 1;  // coefficient row this lane loads
 
-    LaneConst lc;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int v = 0; v < 8; ++v) lc.m[t][v] = 0.25f * cc_of(u, v) * (float)qt.q[t][u * 8 + v];
-        lc.q0[t] = (float)qt.q[t][u * 8];
+    for (int i = tid; i < 128; i += 64) {
+        const int t = i >> 6, k = i & 63;
+        s_m[t][k] = 0.25f * cc_of(k >> 3, k & 7) * (float)qt.q[t][k];
     }
+    LaneConst lc;
+    lc.q0[0] = (float)qt.q[0][u * 8];
+    lc.q0[1] = (float)qt.q[1][u * 8];
     lc.cc0 = cc_of(u, 0);
-    lc.dcmask = (u == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
     if (lane8 < 4) {
-        // even rows 0,2,4,6 live on lanes 0..3; this lane produces E_x, x = lane8
+        // rows 0,2,4,6 live on lanes 0..3; this lane accumulates E_x, x = lane8
 #pragma unroll
         for (int k = 0; k < 4; ++k) lc.k[k] = cosf_tab((2 * lane8 + 1) * (2 * k));
-        lc.s = 1.0f;
     } else {
-        // odd rows 1,3,5,7 live on lanes 4..7; this lane produces -O_x, x = 7 - lane8
+        // rows 1,3,5,7 live on lanes 4..7; this lane accumulates -O_x, x = 7 - lane8
         const int x = 7 - lane8;
 #pragma unroll
         for (int k = 0; k < 4; ++k) lc.k[k] = -cosf_tab((2 * x + 1) * (2 * k + 1));
-        lc.s = 1.0f;
     }
-    // combine: out = own + mirror * s.  Even lane x: E_x + (-(-O_x))  -> s = -1 on even lanes;
-    // odd lane (row 7-x): E_x - O_x = mirror(E_x) * 1 + own(-O_x)   -> s = +1 on odd lanes.
+    // combine: out = own + mirror * s.  Even lane x: E_x - (-O_x) -> s = -1;
+    // odd lane (pixel row 7-x): E_x - O_x = mirror(E_x) + own(-O_x) -> s = +1.
     lc.s = lane8 < 4 ? -1.0f : 1.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
+    // MCU of this lane's group in a tile (groups beyond the image re-read the tile's first MCU;
+    // their pixels are never stored)
+    auto tile_mcu = [&](uint32_t tile) -> size_t {
+        const uint32_t trow = tile / p.tiles_w, tcol = tile - trow * p.tiles_w;
+        const uint32_t m0 = tcol * TILE_MCUS;
+        const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
+        return (size_t)trow * p.mcus_w + m0 + ((uint32_t)grp < nm ? grp : 0);
+    };
+    // coalesced write-back of a finished tile from LDS: 8 rows x nm*24 bytes, 12 bytes per lane and
+    // store.  Issued one iteration late, ahead of the next loads, so that waiting for a tile's
+    // coefficients never waits for the stores that follow them in issue order.
+    auto write_back = [&](uint32_t tile) {
+        const uint32_t trow = tile / p.tiles_w, tcol = tile - trow * p.tiles_w;
+        const uint32_t m0 = tcol * TILE_MCUS;
+        const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
+        uint8_t* base = p.rgb + (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
+#if defined(KPEG_WB_NONE)
+        if (nm == 999) {
+#elif defined(KPEG_WB_X3)
+        if (nm == TILE_MCUS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {  // 8 rows x 16 chunks of 12 bytes = 2 per lane
+                const int c = j * 64 + tid;
+                const int r = c >> 4, k = c & 15;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(s_tile + r * TILE_ROW_STRIDE + k * 12);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(base + (size_t)r * p.pitch + k * 12);
+                const uint32_t x0 = src[0], x1 = src[1], x2 = src[2];
+                asm volatile("global_store_dwordx3 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"((uint3v){x0, x1, x2}) : "memory");
+            }
+#else
+        if (nm == TILE_MCUS && ((reinterpret_cast<uintptr_t>(base) | p.pitch) & 15) == 0) {
+            for (int c = tid; c < 8 * (TILE_ROW_BYTES / 16); c += 64) {  // 8 rows x 12 chunks of 16 bytes
+                const int r = c / (TILE_ROW_BYTES / 16), k = c - r * (TILE_ROW_BYTES / 16);
+                const uint4 val = *reinterpret_cast<const uint4*>(s_tile + r * TILE_ROW_STRIDE + k * 16);
+                *reinterpret_cast<uint4*>(base + (size_t)r * p.pitch + k * 16) = val;
+            }
+#endif
+        } else {
+            const uint32_t per_row = nm * 6;  // 4-byte pieces
+            for (uint32_t c = tid; c < 8 * per_row; c += 64) {
+                const uint32_t r = c / per_row, k = c - r * per_row;
+                *reinterpret_cast<uint32_t*>(base + (size_t)r * p.pitch + k * 4) =
+                    *reinterpret_cast<const uint32_t*>(s_tile + r * TILE_ROW_STRIDE + k * 4);
+            }
+        }
+    };
+
+    uint32_t prev_tile = 0xFFFFFFFFu;
+    uint32_t nq_total = 0;
     for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const uint32_t trow = tile / p.tiles_w, tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
         const bool active = (uint32_t)grp < nm;
+        const size_t mcu = tile_mcu(tile);
+        const uint4* src = reinterpret_cast<const uint4*>(p.coef) + mcu * 24 + u;
+#ifdef KPEG_ABLATE_LOADS
+        const uint4 d0 = make_uint4(tile, 1, 2, 3), d1 = make_uint4(4, tile, 6, 7), d2 = make_uint4(8, 9, tile, 11);
+        const float e0 = 1e-4f, e1 = 1e-4f, e2 = 1e-4f; (void)src;
+#else
+        const uint4 d0 = src[0], d1 = src[8], d2 = src[16];
+        const float e0 = p.ebound[mcu * 3], e1 = p.ebound[mcu * 3 + 1], e2 = p.ebound[mcu * 3 + 2];
+#endif
 
-        if (tid == 0) s_qcount = 0;
-
+        if (prev_tile != 0xFFFFFFFFu) write_back(prev_tile);  // LDS still holds the previous tile
+        prev_tile = tile;
         float v[3][8];
-        float thr[3];
-        {
-            const size_t mcu = (size_t)trow * p.mcus_w + m0 + (active ? grp : 0);
-            const uint4* src = reinterpret_cast<const uint4*>(p.coef) + mcu * 24 + u;
-            uint4 d0 = src[0], d1 = src[8], d2 = src[16];
-            thr[0] = block_fast(d0, lc, 0, v[0]);
-            thr[1] = block_fast(d1, lc, 1, v[1]);
-            thr[2] = block_fast(d2, lc, 1, v[2]);
-        }
-        __syncthreads();  // s_qcount reset visible; previous iteration's tile reads done
+        block_fast(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        block_fast(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        block_fast(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        const float thr0 = 0.5f - e0, thr1 = 0.5f - e1, thr2 = 0.5f - e2;
 
-        // level shift + colour for the 8 pixels of this lane's row
-        float fmaxv[3] = {0.f, 0.f, 0.f};
-        float amaxY = 0.f, amaxC = 0.f, gmin = 1.0f;
-        uint32_t packed[6];
-        uint32_t bytes[8];
+        // Level shift + colour for the 8 pixels of this lane's row.  Per pixel one float key says
+        // whether the reference-order evaluation is needed (key >= 0): a fast value within its block's
+        // bound of a rounding boundary, or a G term too close to an integer for the f32 arithmetic.
+        // Nearly every wavefront has a few such pixels (true ties are structural: equal and opposite
+        // (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5 exactly), so they are
+        // queued straight from this loop with ballot compaction: no atomics, no second pass.
+        float amaxY = 0.f, amaxC = 0.f;
+        uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t nq = 0;
+        const uint32_t ent_lane = (uint32_t)grp | ((uint32_t)lane8 << 5);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float ry = __builtin_rintf(v[0][i]), rb = __builtin_rintf(v[1][i]), rr = __builtin_rintf(v[2][i]);
-            fmaxv[0] = fmaxf(fmaxv[0], fabsf(v[0][i] - ry));
-            fmaxv[1] = fmaxf(fmaxv[1], fabsf(v[1][i] - rb));
-            fmaxv[2] = fmaxf(fmaxv[2], fabsf(v[2][i] - rr));
-            amaxY = fmaxf(amaxY, fabsf(v[0][i]));
-            amaxC = fmaxf(amaxC, fmaxf(fabsf(v[1][i]), fabsf(v[2][i])));
-            float yf = ry + 128.0f;
-            float R = yf + floorf(rr * 1.402f);
-            float B = yf + floorf(rb * 1.772f);
-            float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
-            float G = yf - ceilf(t);
-            float dt = fabsf(t - __builtin_rintf(t));
-            dt = (t == 0.0f) ? 1.0f : dt;
-            gmin = fminf(gmin, dt);
-            int Ri = (int)fminf(fmaxf(R, 0.f), 255.f);
-            int Gi = (int)fminf(fmaxf(G, 0.f), 255.f);
-            int Bi = (int)fminf(fmaxf(B, 0.f), 255.f);
-            bytes[i] = (uint32_t)Ri | ((uint32_t)Gi << 8) | ((uint32_t)Bi << 16);
+            const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
+            const float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
+            const float fy = fabsf(vy - ry) - thr0, fb = fabsf(vb - rb) - thr1, fr = fabsf(vr - rr) - thr2;
+            amaxY = fmaxf(amaxY, fabsf(ry));
+            amaxC = fmaxf(amaxC, fmaxf(fabsf(rb), fabsf(rr)));
+            const float yf = ry + 128.0f;
+            const float R = yf + floorf(rr * 1.402f);
+            const float B = yf + floorf(rb * 1.772f);
+            const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
+            const float G = yf - ceilf(t);
+            // distance of t to the nearest integer, except that t == 0 (Cb = Cr = 128, exact in the
+            // reference too) must not count: non-zero |t| is >= 8e-6, so 1 - |t| * 2^17 <= 0 there
+            const float dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
+            const float key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
+            pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
+            pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
+            pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
+#ifndef KPEG_ABLATE_PUSH
+            const bool push = active && key >= 0.0f;
+            const unsigned long long bal = __ballot(push);
+            if (bal) {  // wave-uniform
+                const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                if (push) {
+                    // entry.x: [2:0] mcu in tile, [7:5] pixel row, [10:8] pixel col, [13:11] components to
+                    // re-evaluate, [31:16] rint(vY); entry.y: rint(vCb) | rint(vCr) << 16 (all |.| < 32000)
+                    const uint32_t mask = (fy >= 0.0f ? 1u : 0u) | (fb >= 0.0f ? 2u : 0u) | (fr >= 0.0f ? 4u : 0u);
+                    s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (mask << 11) | ((uint32_t)(int)ry << 16),
+                                               ((uint32_t)(int)rb & 0xFFFFu) | ((uint32_t)(int)rr << 16));
+                }
+                nq += __popcll(bal);
+            }
+#else
+            (void)key;
+#endif
         }
-        // 8 x 3 bytes -> 6 dwords
-        packed[0] = bytes[0] | (bytes[1] << 24);
-        packed[1] = (bytes[1] >> 8) | (bytes[2] << 16);
-        packed[2] = (bytes[2] >> 16) | (bytes[3] << 8);
-        packed[3] = bytes[4] | (bytes[5] << 24);
-        packed[4] = (bytes[5] >> 8) | (bytes[6] << 16);
-        packed[5] = (bytes[6] >> 16) | (bytes[7] << 8);
 
-        if (active) {
+        {
+            // 24 bytes of pixel row lane8, MCU grp (groups beyond nm write garbage that is never stored)
             uint2* dst = reinterpret_cast<uint2*>(s_tile + lane8 * TILE_ROW_STRIDE + grp * 24);
-            dst[0] = make_uint2(packed[0], packed[1]);
-            dst[1] = make_uint2(packed[2], packed[3]);
-            dst[2] = make_uint2(packed[4], packed[5]);
+            dst[0] = make_uint2(pk[0], pk[1]);
+            dst[1] = make_uint2(pk[2], pk[3]);
+            dst[2] = make_uint2(pk[4], pk[5]);
         }
 
-        const bool suspicious = (fmaxv[0] >= thr[0]) | (fmaxv[1] >= thr[1]) | (fmaxv[2] >= thr[2]) |
-                                (amaxY >= KPEG_LUMA_LIM) | (amaxC >= KPEG_CHROMA_LIM) | (gmin < KPEG_G_DELTA);
-        if (suspicious && active) {
+        // operands outside the range the f32 colour arithmetic is proven for (never seen on real
+        // images): queue the lane's whole row, every component
+        if (__any(active && (amaxY >= KPEG_LUMA_LIM || amaxC >= KPEG_CHROMA_LIM))) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float ry = __builtin_rintf(v[0][i]), rb = __builtin_rintf(v[1][i]), rr = __builtin_rintf(v[2][i]);
-                uint32_t mask = 0;
-                if (fabsf(v[0][i] - ry) >= thr[0] || fabsf(v[0][i]) >= KPEG_LUMA_LIM) mask |= 1;
-                if (fabsf(v[1][i] - rb) >= thr[1] || fabsf(v[1][i]) >= KPEG_CHROMA_LIM) mask |= 2;
-                if (fabsf(v[2][i] - rr) >= thr[2] || fabsf(v[2][i]) >= KPEG_CHROMA_LIM) mask |= 4;
-                float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
-                float dt = fabsf(t - __builtin_rintf(t));
-                bool colour = (t != 0.0f) && (dt < KPEG_G_DELTA);
-                if (mask || colour) {
-                    uint32_t slot = atomicAdd(&s_qcount, 1u);
-                    // entry: [4:0] mcu in tile, [7:5] row, [10:8] col, [13:11] comps to re-evaluate
-                    s_queue[slot] = (uint32_t)grp | ((uint32_t)lane8 << 5) | ((uint32_t)i << 8) | (mask << 11);
-                }
+                const bool push = active && (amaxY >= KPEG_LUMA_LIM || amaxC >= KPEG_CHROMA_LIM);
+                const unsigned long long bal = __ballot(push);
+                const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                if (push) s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (7u << 11), 0u);
+                nq += __popcll(bal);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 
-        // exact re-evaluation, one wavefront per queued pixel
-        const uint32_t nq = s_qcount;
-        if (nq) {
-            const int wave = tid >> 6, lane = tid & 63;
-            for (uint32_t e = wave; e < nq; e += 4) {
-                const uint32_t ent = s_queue[e];
-                const int g = ent & 31, x = (ent >> 5) & 7, y = (ent >> 8) & 7;
-                const size_t mcu = (size_t)trow * p.mcus_w + m0 + g;
-                int S[3];
+        // exact re-evaluation by the whole wavefront, one queued pixel at a time, flagged components only
+        if (nq && !p.skip_exact) {
+            for (uint32_t e = 0; e < nq; ++e) {
+                const uint2 ent = s_queue[e];
+                const int g = ent.x & 7, x = (ent.x >> 5) & 7, y = (ent.x >> 8) & 7;
+                const uint32_t mask = (ent.x >> 11) & 7;
+                const size_t emcu = (size_t)trow * p.mcus_w + m0 + g;
+                // unflagged components: rint(fast value) is provably the reference's rounding
+                int S[3] = {(int)(short)(ent.x >> 16) + 128, (int)(short)(ent.y & 0xFFFF) + 128, (int)(short)(ent.y >> 16) + 128};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    // every component is re-evaluated: the fast value of an unflagged one is
-                    // provably the same, and the pixel needs all three as integers anyway
-                    int F = (int)p.coef[(mcu * 3 + c) * 64 + lane] * (int)qt.q[c ? 1 : 0][lane];
-                    S[c] = exact_sample_wave(F, x, y);
+                    if (mask & (1u << c)) {  // wave-uniform
+                        const int F = (int)p.coef[(emcu * 3 + c) * 64 + tid] * (int)qt.q[c ? 1 : 0][tid];
+                        S[c] = exact_sample_wave(F, x, y);
+                    }
                 }
-                if (lane == 0) {
-                    uint32_t px = colour_exact(S[0], S[1], S[2]);
+                if (tid == 0) {
+                    const uint32_t px = colour_exact(S[0], S[1], S[2]);
                     uint8_t* o = s_tile + x * TILE_ROW_STRIDE + g * 24 + y * 3;
                     o[0] = (uint8_t)px;
                     o[1] = (uint8_t)(px >> 8);
                     o[2] = (uint8_t)(px >> 16);
                 }
             }
-            if (tid == 0 && p.stats) atomicAdd(p.stats, nq);
-            __syncthreads();
         }
-
-        // coalesced write-back of the tile: 8 rows x nm*24 bytes
-        {
-            uint8_t* base = p.rgb + (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
-            const uint32_t row_bytes = nm * 24;
-            if (nm == TILE_MCUS && ((reinterpret_cast<uintptr_t>(base) | p.pitch) & 15) == 0) {
-                for (int c = tid; c < 8 * (TILE_ROW_BYTES / 16); c += 256) {
-                    int r = c / (TILE_ROW_BYTES / 16), k = c - r * (TILE_ROW_BYTES / 16);
-                    uint4 val = *reinterpret_cast<const uint4*>(s_tile + r * TILE_ROW_STRIDE + k * 16);
-                    *reinterpret_cast<uint4*>(base + (size_t)r * p.pitch + k * 16) = val;
-                }
-            } else {
-                const uint32_t per_row = row_bytes / 8;
-                for (uint32_t c = tid; c < 8 * per_row; c += 256) {
-                    uint32_t r = c / per_row, k = c - r * per_row;
-                    uint2 val = *reinterpret_cast<const uint2*>(s_tile + r * TILE_ROW_STRIDE + k * 8);
-                    *reinterpret_cast<uint2*>(base + (size_t)r * p.pitch + k * 8) = val;
-                }
-            }
-        }
-        // the next iteration's first barrier orders these LDS reads before the next writes
+        nq_total += nq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the next iteration writes this tile back before its own colour phase overwrites the LDS tile
     }
+    if (prev_tile != 0xFFFFFFFFu) write_back(prev_tile);
+    // one fire-and-forget add per wavefront, spread over 256 words (a single hot word serialises in L2)
+    if (tid == 0 && nq_total && p.stats) atomicAdd(&p.stats[blockIdx.x & 255], nq_total);
 }
 
 }  // namespace kpeg_dev

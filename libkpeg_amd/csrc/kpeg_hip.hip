@@ -19,6 +19,8 @@
 
 using namespace kpeg_dev;
 
+static const size_t STATUS_WORDS = 16 + 256, STATUS_BYTES = STATUS_WORDS * 4;
+
 // ---------------------------------------------------------------------------------------------
 struct kpeg_hip_ctx {
     int device = 0;
@@ -37,8 +39,11 @@ struct kpeg_hip_ctx {
     size_t scan_cap = 0;
     void* d_rgb = nullptr;
     size_t rgb_cap = 0;
+    void* d_ebound = nullptr;  // per-block error bounds for K4 (written by K2 or k_ebound)
+    size_t ebound_cap = 0;
     EntropyScratch ent;        // K0..K3 work buffers
-    uint32_t* d_status = nullptr;  // [0] exact pixels, [1] entropy error flag, [2] sync rounds
+    // [0] unused, [1] entropy error flag, [2] sync passes, [16..271] K4 exact-pixel counters
+    uint32_t* d_status = nullptr;
     uint32_t* h_status = nullptr;  // pinned mirror
 
     enum { EV_BEGIN, EV_UNSTUFF, EV_SYNC, EV_SCAN, EV_WRITE, EV_DC, EV_IDCT, EV_COUNT };
@@ -124,9 +129,9 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < kpeg_hip_ctx::EV_COUNT; ++i)
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
-    if ((e = hipMalloc((void**)&ctx->d_status, 64)) != hipSuccess) return fail("hipMalloc", e);
-    if ((e = hipHostMalloc((void**)&ctx->h_status, 64, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
-    std::memset(ctx->h_status, 0, 64);
+    if ((e = hipMalloc((void**)&ctx->d_status, STATUS_BYTES)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&ctx->h_status, STATUS_BYTES, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+    std::memset(ctx->h_status, 0, STATUS_BYTES);
     *out = ctx;
     return KPEG_HIP_OK;
 }
@@ -139,6 +144,7 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     if (ctx->d_coef) (void)hipFree(ctx->d_coef);
     if (ctx->d_scan) (void)hipFree(ctx->d_scan);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->d_ebound) (void)hipFree(ctx->d_ebound);
     entropy_scratch_free(&ctx->ent);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -164,7 +170,7 @@ extern "C" int kpeg_hip_set_profiling(kpeg_hip_ctx* ctx, int enable)
 
 extern "C" int kpeg_hip_set_idct_mode(kpeg_hip_ctx* ctx, int mode)
 {
-    if (!ctx || mode < 0 || mode > 1) return KPEG_HIP_E_ARG;
+    if (!ctx || mode < 0 || mode > 2) return KPEG_HIP_E_ARG;
     ctx->idct_mode = mode;
     return KPEG_HIP_OK;
 }
@@ -189,7 +195,9 @@ extern "C" int kpeg_hip_sync(kpeg_hip_ctx* ctx)
     int rc = KPEG_HIP_OK;
     if (ctx->status_pending) {
         ctx->status_pending = false;
-        ctx->timings.exact_pixels = ctx->h_status[0];
+        uint32_t ex = 0;
+        for (int i = 0; i < 256; ++i) ex += ctx->h_status[16 + i];
+        ctx->timings.exact_pixels = ex;
         ctx->timings.sync_rounds = ctx->h_status[2];
         if (ctx->h_status[1] != 0) {
             ctx->last_error = "entropy decode flagged the stream as invalid (code " + std::to_string(ctx->h_status[1]) + ")";
@@ -239,7 +247,7 @@ static void natural_qtables(const kpeg_frame* f, QTables* qt)
         for (int k = 0; k < 64; ++k) qt->q[t][KPEG_ZZ_TO_NATURAL[k]] = f->qt[t][k];
 }
 
-// K4 launch: rows [0, mcu_rows) of d_coef -> d_rgb
+// K4 launch: rows [0, mcu_rows) of d_coef -> d_rgb.  ctx->d_ebound must hold the blocks' error bounds.
 static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_coef, uint8_t* d_rgb, uint32_t mcu_rows)
 {
     if ((reinterpret_cast<uintptr_t>(d_coef) & 15) || (reinterpret_cast<uintptr_t>(d_rgb) & 7)) {
@@ -250,18 +258,23 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     natural_qtables(f, &qt);
     IdctParams p;
     p.coef = d_coef;
+    p.ebound = (const float*)ctx->d_ebound;
     p.rgb = d_rgb;
     p.mcus_w = f->width / 8;
     p.mcu_rows = mcu_rows;
     p.pitch = f->width * 3;
-    p.tiles_w = (p.mcus_w + TILE_MCUS - 1) / TILE_MCUS;
-    p.ntiles = p.tiles_w * mcu_rows;
-    p.stats = ctx->d_status;
+    p.stats = ctx->d_status + 16;
+    p.skip_exact = ctx->idct_mode == 2;
     if (ctx->idct_mode == 1) {
+        p.tiles_w = 0;
+        p.ntiles = 0;
         hipLaunchKernelGGL(k_idct_colour_exact, dim3(p.mcus_w * mcu_rows), dim3(64), 0, ctx->stream, p, qt);
     } else {
-        uint32_t grid = p.ntiles < (uint32_t)ctx->num_cus * 8 ? p.ntiles : (uint32_t)ctx->num_cus * 8;
-        hipLaunchKernelGGL(k_idct_colour_fast, dim3(grid), dim3(256), 0, ctx->stream, p, qt);
+        p.tiles_w = (p.mcus_w + TILE_MCUS - 1) / TILE_MCUS;
+        p.ntiles = p.tiles_w * mcu_rows;
+        const uint32_t resident = (uint32_t)ctx->num_cus * K4_WAVES_PER_CU;  // one wavefront per workgroup
+        const uint32_t grid = p.ntiles < resident ? p.ntiles : resident;
+        hipLaunchKernelGGL(k_idct_colour_fast, dim3(grid), dim3(64), 0, ctx->stream, p, qt);
     }
     HIPCHK(ctx, hipGetLastError());
     return KPEG_HIP_OK;
@@ -269,7 +282,7 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
 
 static int finish_async(kpeg_hip_ctx* ctx)
 {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, STATUS_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     ctx->status_pending = true;
     return KPEG_HIP_OK;
 }
@@ -281,8 +294,18 @@ extern "C" int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, 
     if (!d_coef || !d_rgb) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     begin_call(ctx);
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream));
+    const uint32_t nblocks = (f->width / 8) * (f->height / 8) * 3;
+    if ((rc = grow(ctx, &ctx->d_ebound, &ctx->ebound_cap, (size_t)nblocks * sizeof(float)))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
+    {
+        // caller-supplied coefficients carry no error bounds: derive them (K2 does this on the decode path)
+        QTables qt;
+        natural_qtables(f, &qt);
+        hipLaunchKernelGGL(k_ebound, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, d_coef, nblocks, qt,
+                           (float*)ctx->d_ebound);
+    }
+    mark(ctx, kpeg_hip_ctx::EV_DC);
     rc = launch_idct(ctx, f, d_coef, d_rgb, f->height / 8);
     if (rc) return rc;
     mark(ctx, kpeg_hip_ctx::EV_IDCT);
@@ -318,6 +341,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
         ctx->last_error = "Huffman table is not a usable prefix code";
         return KPEG_HIP_E_TABLES;
     }
+    if ((rc = grow(ctx, &ctx->d_ebound, &ctx->ebound_cap, (size_t)nmcu * 3 * sizeof(float)))) return rc;
     EntropyLaunch L;
     L.stream = ctx->stream;
     L.d_scan = d_scan;
@@ -325,6 +349,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.nmcu = nmcu;
     L.restart_interval = f->restart_interval;
     L.d_coef = d_coef;
+    L.d_ebound = (float*)ctx->d_ebound;
     L.d_status = ctx->d_status;
     L.num_cus = ctx->num_cus;
     L.sync_passes = ctx->sync_passes;
@@ -341,7 +366,7 @@ extern "C" int kpeg_hip_entropy_decode_dev(kpeg_hip_ctx* ctx, const kpeg_frame* 
     if (!d_scan || !scan_len || !d_coef) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     begin_call(ctx);
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     rc = run_entropy(ctx, f, d_scan, scan_len, (f->width / 8) * (f->height / 8), d_coef);
     if (rc) return rc;
@@ -368,7 +393,7 @@ extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f
     const size_t nmcu = (size_t)mw * mcu_rows;
     if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
     begin_call(ctx);
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, 16, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     rc = run_entropy(ctx, f, d_scan, scan_len, (uint32_t)nmcu, (int16_t*)ctx->d_coef);
     if (rc) return rc;

@@ -1,0 +1,109 @@
+// tools/ubench/valu_rate.hip -- issue cost of the VALU instructions K4 is built from (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip ; run on the GPU box.
+// For each instruction: ITER x 64 independent instances per wave; W waves per SIMD.
+// Prints cycles per instruction per SIMD = elapsed_cycles * (#SIMD-resident waves share) / count.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP8(X) X X X X X X X X
+#define BODY(INS)                                                                              \
+    for (int it = 0; it < iters; ++it) {                                                       \
+        asm volatile(REP8(INS "\n\t") REP8(INS "\n\t") REP8(INS "\n\t") REP8(INS "\n\t")          \
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) \
+                     : "v"(c0), "v"(c1));                                                     \
+    }
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long long* cyc)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    float2v b0 = {a0, a1}, b1 = {a1, a2}, b2 = {a2, a3}, b3 = {a3, a0};
+    float c0 = 1.0001f;
+    float2v c1 = {0.9999f, 1.0001f};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (WHICH == 0) { BODY("v_fma_f32 %0, %0, %8, %1") }
+    if (WHICH == 1) { BODY("v_pk_fma_f32 %4, %4, %9, %5") }
+    if (WHICH == 2) { BODY("v_pk_mul_f32 %4, %4, %9") }
+    if (WHICH == 3) { BODY("v_pk_add_f32 %4, %4, %9") }
+    if (WHICH == 4) { BODY("v_mul_f32_dpp %0, %1, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf") }
+    if (WHICH == 5) { BODY("v_fmac_f32_dpp %0, %1, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf") }
+    if (WHICH == 6) { BODY("v_rndne_f32 %0, %1") }
+    if (WHICH == 7) { BODY("v_floor_f32 %0, %1") }
+    if (WHICH == 8) { BODY("v_cvt_pk_u8_f32 %0, %1, 1, %0") }
+    if (WHICH == 9) { BODY("v_cvt_f32_i32 %0, %1") }
+    if (WHICH == 10) { BODY("v_max_f32 %0, %0, %1") }
+    if (WHICH == 11) { BODY("v_add_f32 %0, %0, %8") }
+    if (WHICH == 12) { BODY("v_mul_f32 %0, %0, %8") }
+    if (WHICH == 13) { BODY("v_fmac_f32 %0, %1, %8") }
+    if (WHICH == 14) { BODY("v_max3_f32 %0, %0, %1, %2") }
+    if (WHICH == 15) { BODY("v_fmac_f32_dpp %0, %0, %8 row_half_mirror row_mask:0xf bank_mask:0xf") }
+    if (WHICH == 16) { BODY("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD src0_sel:WORD_1") }
+    if (WHICH == 17) { BODY("v_cndmask_b32 %0, %1, %2, vcc") }
+    if (WHICH == 18) { BODY("v_cmp_eq_f32 vcc, %0, %1") }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + b0.x + b1.y + b2.x + b3.y;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int WHICH>
+void run(const char* name, int wavesPerSimd)
+{
+    const int iters = 2000, ncu = 256;
+    float* out;
+    unsigned long long* cyc;
+    hipMalloc(&out, (size_t)ncu * wavesPerSimd * 256 * 4);
+    hipMalloc(&cyc, (size_t)ncu * wavesPerSimd * 8);
+    hipLaunchKernelGGL(k<WHICH>, dim3(ncu * wavesPerSimd), dim3(256), 0, 0, 10, out, cyc);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<WHICH>, dim3(ncu * wavesPerSimd), dim3(256), 0, 0, iters, out, cyc);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(ncu * wavesPerSimd);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (auto v : h) avg += (double)v;
+    avg /= h.size();
+    const double n = (double)iters * 32;  // instructions per wave
+    // s_memtime ticks = shader cycles; all W waves of a SIMD run concurrently, so per-SIMD
+    // throughput cost = wave cycles / (instructions of one wave * W)
+    printf("%-28s W=%d  wave-cycles/instr %.2f  SIMD-cycles/instr %.2f  (kernel %.3f ms)\n", name, wavesPerSimd, avg / n,
+           avg / n / wavesPerSimd, ms);
+    hipFree(out);
+    hipFree(cyc);
+}
+
+int main()
+{
+    for (int w : {1, 2, 4}) {
+        run<0>("v_fma_f32", w);
+        run<13>("v_fmac_f32", w);
+        run<11>("v_add_f32", w);
+        run<12>("v_mul_f32", w);
+        run<1>("v_pk_fma_f32", w);
+        run<2>("v_pk_mul_f32", w);
+        run<3>("v_pk_add_f32", w);
+        run<4>("v_mul_f32_dpp quad", w);
+        run<5>("v_fmac_f32_dpp quad", w);
+        run<15>("v_fmac_f32_dpp half_mirror", w);
+        run<6>("v_rndne_f32", w);
+        run<7>("v_floor_f32", w);
+        run<8>("v_cvt_pk_u8_f32", w);
+        run<9>("v_cvt_f32_i32", w);
+        run<16>("v_cvt_f32_i32_sdwa", w);
+        run<10>("v_max_f32", w);
+        run<14>("v_max3_f32", w);
+        run<17>("v_cndmask_b32", w);
+        run<18>("v_cmp_eq_f32", w);
+        printf("\n");
+    }
+    return 0;
+}
