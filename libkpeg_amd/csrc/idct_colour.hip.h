@@ -137,6 +137,28 @@ __device__ __forceinline__ int exact_sample_wave(int F, int x, int y)
     return level_shift(ic);
 }
 
+// Same, with the cosine table and the term's float factor supplied by the caller (K4 keeps the
+// tile's coefficients, the quantisers and the cosines in LDS: no global access on this path).
+__device__ __forceinline__ int exact_sample_wave_lds(float fc, const double* __restrict__ s_cos, int x, int y, bool nz)
+{
+    const int lane = __lane_id();
+    const int u = lane >> 3, v = lane & 7;
+    double t = ((double)fc * s_cos[x * 8 + u]) * s_cos[y * 8 + v];
+    unsigned long long live = __ballot(nz);
+    float sum = 0.0f;
+    while (live) {
+        int p = __builtin_ctzll(live);
+        live &= live - 1;
+        long long tb = __builtin_bit_cast(long long, t);
+        unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)tb, p);
+        unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), p);
+        double tp = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        sum = (float)((double)sum + tp);
+    }
+    float ic = (float)(0.25 * (double)sum);
+    return level_shift(ic);
+}
+
 // ---- mode 1: reference-order evaluation of every sample (cross-check kernel) -----------
 // One 64-thread block per MCU, thread = pixel.  Slow by design.
 __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables qt)
@@ -221,12 +243,18 @@ __global__ __launch_bounds__(256) void k_ebound(const int16_t* coef, uint32_t nb
 }
 
 typedef unsigned int uint3v __attribute__((ext_vector_type(3)));
+// int16 element k of a coefficient array kept as 32-bit words
+__device__ __forceinline__ int lds_coef(const uint32_t* w, int k)
+{
+    const uint32_t x = w[k >> 1];
+    return (k & 1) ? ((int)x >> 16) : (int)(short)(x & 0xFFFF);
+}
 constexpr int TILE_MCUS = 8;                    // MCUs per wavefront iteration (8 lane groups)
 constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 192
 constexpr int TILE_ROW_STRIDE = 208;            // padded: 13 x 16 bytes, conflict-free b64 writes across rows
-constexpr int QUEUE_CAP = TILE_MCUS * 64 * 2;   // every pixel of the tile, twice (range pass)
+constexpr int QUEUE_CAP = 256;                  // queued pixels per tile; more -> whole-tile exact path
 #ifndef KPEG_K4_OCC
-#define KPEG_K4_OCC 6
+#define KPEG_K4_OCC 8
 #endif
 constexpr int K4_WAVES_PER_CU = 4 * KPEG_K4_OCC;  // one wavefront per workgroup, KPEG_K4_OCC per SIMD
 
@@ -356,6 +384,9 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[8 * TILE_ROW_STRIDE];
     __shared__ uint2 s_queue[QUEUE_CAP];
     __shared__ __attribute__((aligned(16))) float s_m[2][64];  // AC input scales, natural order
+    __shared__ __attribute__((aligned(16))) uint32_t s_coef[TILE_MCUS * 96];  // the tile's coefficients (exact path)
+    __shared__ float s_qcc[2][64];                              // (float)Q (exact dequantisation on the exact path)
+    __shared__ double s_cos[64];
 
     const int tid = threadIdx.x;
     const int lane8 = tid & 7;          // lane within the MCU group = output pixel row
@@ -365,7 +396,9 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     for (int i = tid; i < 128; i += 64) {
         const int t = i >> 6, k = i & 63;
         s_m[t][k] = 0.25f * cc_of(k >> 3, k & 7) * (float)qt.q[t][k];
+        s_qcc[t][k] = (float)qt.q[t][k];
     }
+    s_cos[tid] = c_cos[tid];
     LaneConst lc;
     lc.q0[0] = (float)qt.q[0][u * 8];
     lc.q0[1] = (float)qt.q[1][u * 8];
@@ -452,6 +485,14 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
 
         if (prev_tile != 0xFFFFFFFFu) write_back(prev_tile);  // LDS still holds the previous tile
         prev_tile = tile;
+        {
+            // keep the tile's coefficients at hand for the exact path: block (grp, c), row u
+            // (plain uint32_t accesses on both sides: no type punning)
+            uint32_t* sc = s_coef + ((grp * 3) * 8 + u) * 4;
+            sc[0] = d0.x, sc[1] = d0.y, sc[2] = d0.z, sc[3] = d0.w;
+            sc[32] = d1.x, sc[33] = d1.y, sc[34] = d1.z, sc[35] = d1.w;
+            sc[64] = d2.x, sc[65] = d2.y, sc[66] = d2.z, sc[67] = d2.w;
+        }
         float v[3][8];
         block_fast(d0, lc, &s_m[0][u * 8], 0, v[0]);
         block_fast(d1, lc, &s_m[1][u * 8], 1, v[1]);
@@ -492,7 +533,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             const unsigned long long bal = __ballot(push);
             if (bal) {  // wave-uniform
                 const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                if (push) {
+                if (push && slot < QUEUE_CAP) {
                     // entry.x: [2:0] mcu in tile, [7:5] pixel row, [10:8] pixel col, [13:11] components to
                     // re-evaluate, [31:16] rint(vY); entry.y: rint(vCb) | rint(vCr) << 16 (all |.| < 32000)
                     const uint32_t mask = (fy >= 0.0f ? 1u : 0u) | (fb >= 0.0f ? 2u : 0u) | (fr >= 0.0f ? 4u : 0u);
@@ -522,7 +563,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 const bool push = active && (amaxY >= KPEG_LUMA_LIM || amaxC >= KPEG_CHROMA_LIM);
                 const unsigned long long bal = __ballot(push);
                 const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                if (push) s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (7u << 11), 0u);
+                if (push && slot < QUEUE_CAP) s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (7u << 11), 0u);
                 nq += __popcll(bal);
             }
         }
@@ -531,26 +572,54 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
 
         // exact re-evaluation by the whole wavefront, one queued pixel at a time, flagged components only
         if (nq && !p.skip_exact) {
-            for (uint32_t e = 0; e < nq; ++e) {
-                const uint2 ent = s_queue[e];
-                const int g = ent.x & 7, x = (ent.x >> 5) & 7, y = (ent.x >> 8) & 7;
-                const uint32_t mask = (ent.x >> 11) & 7;
-                const size_t emcu = (size_t)trow * p.mcus_w + m0 + g;
-                // unflagged components: rint(fast value) is provably the reference's rounding
-                int S[3] = {(int)(short)(ent.x >> 16) + 128, (int)(short)(ent.y & 0xFFFF) + 128, (int)(short)(ent.y >> 16) + 128};
+            const float ccl = cc_of(tid >> 3, tid & 7);
+            if (nq > QUEUE_CAP) {
+                // more unsafe pixels than the queue holds (adversarial input): every pixel of the tile
+                for (uint32_t e = 0; e < (uint32_t)nm * 64; ++e) {
+                    const int g = e >> 6, x = (e >> 3) & 7, y = e & 7;
+                    int S[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (mask & (1u << c)) {  // wave-uniform
-                        const int F = (int)p.coef[(emcu * 3 + c) * 64 + tid] * (int)qt.q[c ? 1 : 0][tid];
-                        S[c] = exact_sample_wave(F, x, y);
+                    for (int c = 0; c < 3; ++c) {
+                        // (float)(c * Q) is exact here: the product of two integers below 2^24 ... or rounds like the int would
+                        const int F = lds_coef(s_coef, (g * 3 + c) * 64 + tid) * (int)s_qcc[c ? 1 : 0][tid];
+                        S[c] = exact_sample_wave_lds(ccl * (float)F, s_cos, x, y, F != 0);
+                    }
+                    if (tid == 0) {
+                        const uint32_t px = colour_exact(S[0], S[1], S[2]);
+                        uint8_t* o = s_tile + x * TILE_ROW_STRIDE + g * 24 + y * 3;
+                        o[0] = (uint8_t)px;
+                        o[1] = (uint8_t)(px >> 8);
+                        o[2] = (uint8_t)(px >> 16);
                     }
                 }
-                if (tid == 0) {
-                    const uint32_t px = colour_exact(S[0], S[1], S[2]);
-                    uint8_t* o = s_tile + x * TILE_ROW_STRIDE + g * 24 + y * 3;
-                    o[0] = (uint8_t)px;
-                    o[1] = (uint8_t)(px >> 8);
-                    o[2] = (uint8_t)(px >> 16);
+            } else {
+                for (uint32_t e = 0; e < nq; ++e) {
+                    const uint2 ent = s_queue[e];
+                    const int g = ent.x & 7, x = (ent.x >> 5) & 7, y = (ent.x >> 8) & 7;
+                    const uint32_t mask = (ent.x >> 11) & 7;
+                    // unflagged components: rint(fast value) is provably the reference's rounding
+                    int S[3] = {(int)(short)(ent.x >> 16) + 128, (int)(short)(ent.y & 0xFFFF) + 128, (int)(short)(ent.y >> 16) + 128};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (mask & (1u << c)) {  // wave-uniform
+                            const int F = lds_coef(s_coef, (g * 3 + c) * 64 + tid) * (int)s_qcc[c ? 1 : 0][tid];
+                            S[c] = exact_sample_wave_lds(ccl * (float)F, s_cos, x, y, F != 0);
+#ifdef KPEG_DEBUG_EXACT
+                            if (tile == 1 && e == 0 && p.stats) {
+                                p.stats[64 + tid] = (uint32_t)F;
+                                p.stats[128 + tid] = (uint32_t)p.coef[((size_t)(trow * p.mcus_w + m0 + g) * 3 + c) * 64 + tid];
+                                if (tid == 0) { p.stats[200] = ent.x; p.stats[201] = ent.y; p.stats[202] = (uint32_t)S[c]; p.stats[203] = c; }
+                            }
+#endif
+                        }
+                    }
+                    if (tid == 0) {
+                        const uint32_t px = colour_exact(S[0], S[1], S[2]);
+                        uint8_t* o = s_tile + x * TILE_ROW_STRIDE + g * 24 + y * 3;
+                        o[0] = (uint8_t)px;
+                        o[1] = (uint8_t)(px >> 8);
+                        o[2] = (uint8_t)(px >> 16);
+                    }
                 }
             }
         }

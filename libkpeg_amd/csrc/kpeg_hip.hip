@@ -441,3 +441,11 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
     }
     return KPEG_HIP_OK;
 }
+
+// test hook: raw status words of the last synchronised call
+extern "C" int kpeg_hip_debug_words(kpeg_hip_ctx* ctx, uint32_t* out, int n)
+{
+    if (!ctx || !out) return KPEG_HIP_E_ARG;
+    for (int i = 0; i < n && i < (int)STATUS_WORDS; ++i) out[i] = ctx->h_status[i];
+    return KPEG_HIP_OK;
+}
