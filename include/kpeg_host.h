@@ -34,6 +34,17 @@ int kpeg_host_decode_file(const char* path, unsigned flags);
  * FF of the i-th RSTn.  Returns the number of markers found (may exceed cap; only cap are stored). */
 size_t kpeg_host_restart_offsets(const uint8_t* scan, size_t n, uint64_t* offsets, size_t cap);
 
+/* kpeg::HuffmanTree::contains() on a tree built from (counts, symbols): writes the reference's
+ * answer ("", "EOB" or the decimal symbol) into out.  For the known-answer tests. */
+int kpeg_host_huffman_contains(const uint8_t counts[16], const uint8_t* symbols, const char* bits, char* out, size_t cap);
+
+/* kpeg::bitStringtoValue / valueToBitString / getValueCategory (src/Image.cpp:258-320). */
+int kpeg_host_bitstring_to_value(const char* bits);
+int kpeg_host_value_to_bitstring(int value, char* out, size_t cap);
+
+/* kpeg::isValidFilename (include/Utility.hpp:16-38). */
+int kpeg_host_is_valid_filename(const char* name);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,10 @@
 #include <string>
 
 #include "Decoder.hpp"
+#include "HuffmanTree.hpp"
+#include "Image.hpp"
 #include "Logger.hpp"
+#include "Utility.hpp"
 
 extern "C" int kpeg_host_parse( const uint8_t* file, size_t size, unsigned flags, kpeg_frame* frame, uint8_t* scan, size_t scan_cap,
                                 size_t* scan_len )
@@ -70,3 +73,34 @@ extern "C" size_t kpeg_host_restart_offsets( const uint8_t* scan, size_t n, uint
         }
     return k;
 }
+
+extern "C" int kpeg_host_huffman_contains( const uint8_t counts[16], const uint8_t* symbols, const char* bits, char* out, size_t cap )
+{
+    kpeg::HuffmanTable t;
+    int k = 0;
+    for ( int i = 0; i < 16; ++i )
+    {
+        t[i].first = counts[i];
+        t[i].second.assign( symbols + k, symbols + k + counts[i] );
+        k += counts[i];
+    }
+    kpeg::HuffmanTree tree( t );
+    const std::string r = tree.contains( bits );
+    if ( r.size() + 1 > cap )
+        return -1;
+    std::memcpy( out, r.c_str(), r.size() + 1 );
+    return (int)r.size();
+}
+
+extern "C" int kpeg_host_bitstring_to_value( const char* bits ) { return kpeg::bitStringtoValue( bits ); }
+
+extern "C" int kpeg_host_value_to_bitstring( int value, char* out, size_t cap )
+{
+    const std::string r = kpeg::valueToBitString( (kpeg::Int16)value );
+    if ( r.size() + 1 > cap )
+        return -1;
+    std::memcpy( out, r.c_str(), r.size() + 1 );
+    return (int)r.size();
+}
+
+extern "C" int kpeg_host_is_valid_filename( const char* name ) { return kpeg::isValidFilename( name ) ? 1 : 0; }

@@ -1,0 +1,90 @@
+"""Constant tables and error-bound constants (CPU only)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+import kpeg_testlib as T
+
+CSRC = os.path.join(T.ROOT, "libkpeg_amd", "csrc")
+
+
+def _hex_doubles(text):
+    return [float.fromhex(x) for x in re.findall(r"-?0x1\.[0-9a-f]+p[+-]\d+", text)]
+
+
+def test_cos_table_matches_libm_and_golden():
+    import ctypes
+    t = (ctypes.c_double * 64)()
+    T.oracle().kpeg_oracle_cos_table(t)
+    libm = list(t)
+    golden = [float.fromhex(l) for l in open(os.path.join(T.GOLDEN, "cos_table.hex")).read().split()]
+    assert libm == golden  # this host's glibc agrees with the values captured next to the reference
+    hdr = open(os.path.join(CSRC, "kpeg_tables.h")).read()
+    assert _hex_doubles(hdr.split("KPEG_COS_TABLE")[1].split("};")[0]) == golden
+    dev = open(os.path.join(CSRC, "idct_colour.hip.h")).read()
+    assert _hex_doubles(dev.split("c_cos[64]")[1].split("};")[0]) == golden
+
+
+def test_zigzag_table():
+    std = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    assert list(T.zz_table()) == std
+    hdr = open(os.path.join(CSRC, "kpeg_tables.h")).read()
+    nums = [int(x) for x in re.findall(r"\d+", hdr.split("KPEG_ZZ_TO_NATURAL[64] = {")[1].split("}")[0])]
+    assert nums == std
+
+
+def test_kernel_error_constant_covers_the_derived_bound():
+    """K4's KPEG_KAPPA must be >= the constant tools/idct_bound.py derives from the kernel's own
+    operation sequence (which the script also checks against the exact IDCT kernel)."""
+    sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+    import idct_bound
+    k = idct_bound.kappa()
+    src = open(os.path.join(CSRC, "idct_colour.hip.h")).read()
+    kk = float(re.search(r"#define KPEG_KAPPA ([0-9.]+)f", src).group(1))
+    assert 10.0 < k <= kk < k + 1.0, (k, kk)
+    # K2 writes the same bound formula as block_ebound()
+    ent = open(os.path.join(CSRC, "entropy.hip.h")).read()
+    assert "0x1.004p-24f * Asum) * ((float)nnz + %sf)" % ("%.1f" % kk) in ent
+    assert "#define KPEG_U 0x1.004p-24f" in src
+
+
+def test_fast_path_error_bound_holds_empirically():
+    """float32 emulation of K4's row/column passes vs the oracle's float result: the observed
+    distance stays inside E = U * A * (nnz_ac + KAPPA) on real blocks."""
+    data = T.synth_jpeg(256, 128, seed=8)
+    p = T.oracle_parse(data)
+    rc, coef = T.oracle_entropy(p)
+    nat = T.zz_to_natural(coef)
+    zz = T.zz_table()
+    import ctypes
+    import math
+    C = np.array([[math.cos((2 * x + 1) * u * math.pi / 16) for u in range(8)] for x in range(8)], np.float32)
+    cc = np.ones((8, 8), np.float32)
+    cc[0, :] *= np.float32(float.fromhex('0x1.6a09e6p-1'))
+    cc[:, 0] *= np.float32(float.fromhex('0x1.6a09e6p-1'))
+    worst = 0.0
+    out = np.empty(64, np.float32)
+    for c in range(3):
+        q = np.zeros(64, np.float32)
+        q[zz] = p.qt[0 if c == 0 else 1].astype(np.float32)
+        q = q.reshape(8, 8)
+        for n in range(0, nat.shape[0], 7):
+            blk = nat[n, c].astype(np.float32)
+            inn = (np.float32(0.25) * cc * q) * blk
+            inn[:, 0] = np.float32(0.25) * (cc[:, 0] * (blk[:, 0] * q[:, 0]))
+            fast = (C @ inn.astype(np.float32) @ C.T).astype(np.float32)  # f32 matrix form of the same transform
+            T.oracle().kpeg_oracle_idct_block(np.ascontiguousarray(coef[n, c]).ctypes.data,
+                                              np.ascontiguousarray(p.qt[0 if c == 0 else 1]).ctypes.data, out.ctypes.data)
+            A = float(np.abs(inn).sum())
+            nn = int((blk != 0).sum() - (blk[0, 0] != 0))
+            E = 2.0 ** -24 * A * (nn + 14.5) if nn else 0.0
+            err = float(np.abs(fast.reshape(-1).astype(np.float64) - out.astype(np.float64)).max())
+            if E > 0:
+                worst = max(worst, err / E)
+            else:
+                assert err == 0.0
+    assert worst < 1.0, worst
