@@ -35,13 +35,23 @@
 
 namespace kpeg_dev {
 
-constexpr int SUBSEQ_BITS = 512;  // bits per sub-sequence (tunable; multiple of 32)
+#ifndef KPEG_SUBSEQ_BITS
+#define KPEG_SUBSEQ_BITS 256
+#endif
+constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable; 128, 256, 512 or 1024)
+constexpr int SUBSEQ_WORDS = SUBSEQ_BITS / 32;
 constexpr int LUT_BITS = 9;
 constexpr int SYNC_PASSES = 4;  // sync kernels enqueued per call: pass 0 + boundary passes (idle ones exit at once)
 constexpr int SYNC_WG = 256;    // sub-sequences per workgroup
 
+constexpr int LUT2_BITS = 16 - LUT_BITS;   // remaining bits of a long code
+constexpr int LUT2_SUBS = 12;             // second-level tables per Huffman table (canonical codes need few)
+constexpr uint16_t LUT_LONG = 0x8000;     // first-level entry: code longer than LUT_BITS, low bits = sub-table
+constexpr uint16_t LUT_SEARCH = 0xFFFF;   // ... no sub-table left: canonical search (never for real tables)
+
 struct EntropyTables {  // built on the host per frame, copied to the device when it changes
-    uint16_t lut[4][1 << LUT_BITS];  // [class*2+id]: (len << 8) | symbol, 0 = code longer than LUT_BITS
+    uint16_t lut[4][1 << LUT_BITS];  // [class*2+id]: (len << 8) | symbol; LUT_LONG | sub; 0 = no such code
+    uint16_t lut2[4][LUT2_SUBS][1 << LUT2_BITS];  // (len << 8) | symbol for codes of 10..16 bits; 0 = no such code
     int32_t maxcode[4][18];          // canonical: largest code of each length (-1 if none)
     int32_t valoff[4][18];           // symbol index of the first code of each length minus that code
     uint8_t symbols[4][256];
@@ -67,7 +77,7 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
         for (int id = 0; id < 2; ++id) {
             const kpeg_dht& h = f->dht[cls][id];
             const int ti = cls * 2 + id;
-            int code = 0, k = 0;
+            int code = 0, k = 0, nsub = 0;
             for (int len = 1; len <= 16; ++len) {
                 int cnt = h.counts[len - 1];
                 if (k + cnt > 256) return -1;
@@ -77,9 +87,19 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
                 for (int i = 0; i < cnt; ++i) {
                     uint8_t sym = h.symbols[k];
                     t->symbols[ti][k] = sym;
+                    const uint16_t e = (uint16_t)((len << 8) | sym);
                     if (len <= LUT_BITS) {
                         int first = code << (LUT_BITS - len);
-                        for (int j = 0; j < (1 << (LUT_BITS - len)); ++j) t->lut[ti][first + j] = (uint16_t)((len << 8) | sym);
+                        for (int j = 0; j < (1 << (LUT_BITS - len)); ++j) t->lut[ti][first + j] = e;
+                    } else {
+                        const int prefix = code >> (len - LUT_BITS);
+                        uint16_t& l1 = t->lut[ti][prefix];
+                        if (l1 == 0) l1 = nsub < LUT2_SUBS ? (uint16_t)(LUT_LONG | nsub++) : LUT_SEARCH;
+                        if (l1 != LUT_SEARCH) {
+                            const int sub = l1 & 0x7FFF, rem = len - LUT_BITS;
+                            const int first = (code & ((1 << rem) - 1)) << (LUT2_BITS - rem);
+                            for (int j = 0; j < (1 << (LUT2_BITS - rem)); ++j) t->lut2[ti][sub][first + j] = e;
+                        }
                     }
                     code++;
                     k++;
@@ -354,6 +374,7 @@ __device__ __forceinline__ DecState unpack_state(uint64_t v)
 
 struct LdsTables {
     uint16_t lut[4][1 << LUT_BITS];
+    uint16_t lut2[4][LUT2_SUBS][1 << LUT2_BITS];
     int32_t maxcode[4][18];
     int32_t valoff[4][18];
     uint8_t symbols[4][256];
@@ -370,13 +391,68 @@ __device__ __forceinline__ void load_tables(LdsTables* dst, const EntropyTables*
     for (uint32_t i = threadIdx.x; i < sizeof(LdsTables) / 4; i += blockDim.x) d[i] = s[i];
 }
 
-// 32 bits starting at bit position p (big-endian bit order)
-__device__ __forceinline__ uint32_t peek32(const uint32_t* __restrict__ w, uint32_t p)
+// The bit string as the decode loops see it: the workgroup's slice staged in LDS (a symbol costs
+// two LDS reads instead of two dependent global loads), anything beyond the slice from global memory.
+// LDS word j lives at j + j/SUBSEQ_WORDS: lanes start SUBSEQ_WORDS words apart, the padding spreads
+// them over the banks.
+constexpr int STAGE_WORDS = SYNC_WG * (SUBSEQ_BITS / 32);   // the workgroup's own sub-sequences
+constexpr int STAGE_MARGIN = 512;                           // words of run-over into the next workgroup
+constexpr int STAGE_TOTAL = STAGE_WORDS + STAGE_MARGIN;
+constexpr int STAGE_LDS = STAGE_TOTAL + STAGE_TOTAL / SUBSEQ_WORDS + 2;
+__device__ __forceinline__ uint32_t stage_idx(uint32_t j) { return j + j / SUBSEQ_WORDS; }
+
+struct BitSrc {
+    const uint32_t* __restrict__ g;   // whole un-stuffed string
+    const uint32_t* lds;              // staged slice
+    uint32_t w0;                      // first staged word
+    uint32_t nw;                      // staged words
+};
+
+__device__ __forceinline__ void stage_bits(uint32_t* lds, const uint32_t* __restrict__ g, uint32_t w0, uint32_t nw)
 {
-    uint32_t i = p >> 5, o = p & 31;
-    uint32_t hi = w[i], lo = w[i + 1];
-    return __funnelshift_l(lo, hi, o);
+    for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) lds[stage_idx(j)] = g[w0 + j];
 }
+
+// Word i of the bit string for the decode loops.  Every position a lane can reach lies inside its
+// workgroup's staged slice: a run starts at most one symbol (< 32 bits) before its own sub-sequence
+// and K2 finishes at most one block (< 1728 bits, STAGE_MARGIN is 16384) past it.  Only a corrupt
+// stream can run further; its reads are clamped (the result is flagged as an error elsewhere).
+__device__ __forceinline__ uint32_t src_word(const BitSrc& b, uint32_t i)
+{
+    const uint32_t j = min(i - b.w0, b.nw - 1);
+    return b.lds[stage_idx(j)];
+}
+
+// Sequential reader: the next >= 32 bits sit MSB-aligned in a 64-bit register, so a symbol's
+// critical path is one LUT read, not LUT + two word fetches; the following word is fetched one
+// refill ahead.
+struct BitReader {
+    uint64_t buf;
+    uint32_t have;   // valid bits in buf, >= 32 between symbols
+    uint32_t wi;     // index of the word after `nextw`
+    uint32_t nextw;
+
+    __device__ __forceinline__ void init(const BitSrc& b, uint32_t p)
+    {
+        const uint32_t i = p >> 5, o = p & 31;
+        buf = (((uint64_t)src_word(b, i) << 32) | src_word(b, i + 1)) << o;
+        have = 64 - o;
+        nextw = src_word(b, i + 2);
+        wi = i + 3;
+    }
+    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)(buf >> 32); }
+    __device__ __forceinline__ void consume(const BitSrc& b, uint32_t n)   // n <= 31
+    {
+        buf <<= n;
+        have -= n;
+        if (have <= 32) {
+            buf |= (uint64_t)nextw << (32 - have);
+            have += 32;
+            nextw = src_word(b, wi);
+            wi++;
+        }
+    }
+};
 
 // Decodes one symbol at state s.  Returns false when the code is not in the table (the
 // reference would never leave its bit loop, Decoder.cpp:704-748).
@@ -384,22 +460,27 @@ __device__ __forceinline__ uint32_t peek32(const uint32_t* __restrict__ w, uint3
 __device__ __forceinline__ bool decode_symbol(const LdsTables& T, uint32_t win, int ti, uint32_t& sym, uint32_t& len)
 {
     uint32_t e = T.lut[ti][win >> (32 - LUT_BITS)];
-    if (e) {
-        sym = e & 0xFF;
-        len = e >> 8;
-        return true;
-    }
-    for (int l = LUT_BITS + 1; l <= 16; ++l) {
-        int code = (int)(win >> (32 - l));
-        if (code <= T.maxcode[ti][l]) {
-            sym = T.symbols[ti][(T.valoff[ti][l] + code) & 255];
-            len = l;
-            return true;
+    if (e & LUT_LONG) {  // 10..16-bit code: one more table read
+        if (e != LUT_SEARCH) {
+            e = T.lut2[ti][e & 0x7FFF][(win >> (32 - 16)) & ((1 << LUT2_BITS) - 1)];
+        } else {
+            e = 0;
+            for (int l = LUT_BITS + 1; l <= 16; ++l) {
+                int code = (int)(win >> (32 - l));
+                if (code <= T.maxcode[ti][l]) {
+                    e = ((uint32_t)l << 8) | T.symbols[ti][(T.valoff[ti][l] + code) & 255];
+                    break;
+                }
+            }
         }
     }
-    sym = 0;
-    len = 16;
-    return false;
+    sym = e & 0xFF;
+    len = e >> 8;
+    if (e == 0) {
+        len = 16;  // no such code: keep moving (only a speculative decode or a corrupt stream gets here)
+        return false;
+    }
+    return true;
 }
 
 // JPEG EXTEND (bitStringtoValue, Image.cpp:285-302)
@@ -417,40 +498,47 @@ struct RunResult {
 };
 
 // Sync/count run: decode from `s` until the bit position reaches `pend`.
-__device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_t* __restrict__ w, DecState s, uint32_t pend)
+__device__ __forceinline__ RunResult run_count(const LdsTables& T, const BitSrc& w, DecState s, uint32_t pend)
 {
     RunResult r;
     r.nb = 0;
     r.dc[0] = r.dc[1] = r.dc[2] = 0;
-    while (s.p < pend) {
-        uint32_t win = peek32(w, s.p);
+    BitReader br;
+    br.init(w, s.p);
+    uint32_t p = s.p, c = s.c, k = s.k;
+    int nb = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    // branch-free state machine: lanes of a wavefront sit at different points of their blocks
+    while (p < pend) {
+        const uint32_t win = br.peek();
+        const uint32_t isac = k != 0;
         uint32_t sym, len;
-        const int ti = (s.k ? 2 : 0) + (s.c ? 1 : 0);
-        decode_symbol(T, win, ti, sym, len);
-        const uint32_t cat = sym & 15, run = sym >> 4;
-        if (s.k == 0) {
-            uint32_t bits = cat ? (win << len) >> (32 - cat) : 0;
-            int d = extend(bits, cat);
-            r.nb++;
-            if (s.c == 0) r.dc[0] += d;
-            else if (s.c == 1) r.dc[1] += d;
-            else r.dc[2] += d;
-            s.p += len + cat;
-            s.k = 1;
-        } else {
-            if (sym == 0) {  // EOB
-                s.p += len;
-                s.k = 64;
-            } else {
-                s.p += len + cat;
-                s.k += run + 1;
-            }
-            if (s.k >= 64) {  // block complete (EOB, or ACCodesCount == 63, Decoder.cpp:759)
-                s.k = 0;
-                s.c = s.c == 2 ? 0 : s.c + 1;
-            }
-        }
+        decode_symbol(T, win, (int)(isac * 2 + (c != 0)), sym, len);
+        const uint32_t cat = sym & 15, run = sym >> 4;   // EOB (symbol 0) has cat 0: it consumes len bits
+        const uint32_t used = len + cat;
+        // DC difference (EXTEND), only counted when this symbol is a DC symbol
+        const uint32_t bits = __builtin_amdgcn_ubfe(win << len, 32 - cat, cat);
+        const uint32_t half = (1u << cat) >> 1;
+        const int d = (int)bits - (bits < half ? (int)((1u << cat) - 1u) : 0);
+        const int dd = isac ? 0 : d;
+        nb += (int)(isac ^ 1u);
+        dc0 += c == 0 ? dd : 0;
+        dc1 += c == 1 ? dd : 0;
+        dc2 += c == 2 ? dd : 0;
+        uint32_t kn = isac ? k + run + 1 : 1u;
+        kn = (isac && sym == 0) ? 64u : kn;       // EOB
+        const bool done = kn >= 64;                // block complete (EOB, or ACCodesCount == 63, Decoder.cpp:759)
+        k = done ? 0u : kn;
+        c = done ? (c == 2 ? 0u : c + 1) : c;
+        p += used;
+        br.consume(w, used);
     }
+    s.p = p;
+    s.c = c;
+    s.k = k;
+    r.nb = nb;
+    r.dc[0] = dc0;
+    r.dc[1] = dc1;
+    r.dc[2] = dc2;
     r.exit_state = pack_state(s);
     return r;
 }
@@ -514,6 +602,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     __shared__ uint64_t s_X[SYNC_WG];
     __shared__ uint8_t s_dirty[SYNC_WG + 1];
     __shared__ int4 s_red[SYNC_WG / 64];
+    __shared__ uint32_t s_bits[STAGE_LDS];
     const uint32_t nsub = a.meta->nsub;
     const int p = a.pass;
     const uint32_t g = blockIdx.x, t = threadIdx.x;
@@ -541,6 +630,17 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     geo.li = 0;
     geo.pstart = geo.pend = 0;
     if (valid) geo = sub_geom(a.seg_off, a.sub_base, nseg, i);
+    // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
+    BitSrc src;
+    {
+        const SubGeom g0 = sub_geom(a.seg_off, a.sub_base, nseg, i0);
+        src.g = a.u;
+        src.lds = s_bits;
+        src.w0 = g0.pstart >> 5;
+        const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
+        src.nw = min((uint32_t)STAGE_TOTAL, total_words > src.w0 ? total_words - src.w0 : 0u);
+        stage_bits(s_bits, a.u, src.w0, src.nw);
+    }
     __syncthreads();
 
     uint64_t myX = 0;
@@ -553,7 +653,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s.p = geo.pstart;
             s.c = 0;
             s.k = 0;
-            RunResult r = run_count(T, a.u, s, geo.pend);
+            RunResult r = run_count(T, src, s, geo.pend);
             myX = r.exit_state;
             mycnt = make_int4(r.nb, r.dc[0], r.dc[1], r.dc[2]);
             dirty = geo.li != 0 && t > 0;
@@ -575,7 +675,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         __syncthreads();
         bool changed = false;
         if (dirty) {
-            RunResult r = run_count(T, a.u, unpack_state(e), geo.pend);
+            RunResult r = run_count(T, src, unpack_state(e), geo.pend);
             changed = r.exit_state != myX;
             myX = r.exit_state;
             mycnt = make_int4(r.nb, r.dc[0], r.dc[1], r.dc[2]);
@@ -701,6 +801,7 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
     __shared__ LdsTables T;
     __shared__ __attribute__((aligned(16))) int16_t s_blk[256 * WB_STRIDE];
     __shared__ int4 s_pre[256];
+    __shared__ uint32_t s_bits[STAGE_LDS];
     const uint32_t nsub = a.meta->nsub;
     if (blockIdx.x * 256u >= nsub) return;
     load_tables(&T, a.tabs);
@@ -711,6 +812,16 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         for (int q = 0; q < 8; ++q) b4[q] = z;
     }
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    BitSrc w;
+    {
+        const SubGeom g0 = sub_geom(a.seg_off, a.sub_base, a.meta->nseg, blockIdx.x * 256u);
+        w.g = a.u;
+        w.lds = s_bits;
+        w.w0 = g0.pstart >> 5;
+        const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
+        w.nw = min((uint32_t)STAGE_TOTAL, total_words > w.w0 ? total_words - w.w0 : 0u);
+        stage_bits(s_bits, a.u, w.w0, w.nw);
+    }
     if (!a.prefix) {
         int4 v = i < nsub ? a.cnt[i] : make_int4(0, 0, 0, 0);
         s_pre[threadIdx.x] = v;
@@ -758,20 +869,24 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
     const uint32_t blk_limit = seg_mcus * 3;       // blocks of this segment
     uint32_t b = (uint32_t)pre.x;                  // next block to start, within the segment
     int pred[3] = {pre.y, pre.z, pre.w};
-    const uint32_t* __restrict__ w = a.u;
     const uint32_t seg_pend = a.seg_off[g.seg + 1] * 8;
 
+    BitReader br;
+    br.init(w, s.p);
     // a block that began in an earlier sub-sequence belongs to the lane that started it
     while (s.k != 0 && s.p < seg_pend) {
-        uint32_t win = peek32(w, s.p), sym, len;
-        decode_symbol(T, win, 2 + (s.c ? 1 : 0), sym, len);
+        uint32_t sym, len;
+        decode_symbol(T, br.peek(), 2 + (s.c ? 1 : 0), sym, len);
+        uint32_t used;
         if (sym == 0) {
-            s.p += len;
+            used = len;
             s.k = 64;
         } else {
-            s.p += len + (sym & 15);
+            used = len + (sym & 15);
             s.k += (sym >> 4) + 1;
         }
+        s.p += used;
+        br.consume(w, used);
         if (s.k >= 64) {
             s.k = 0;
             s.c = s.c == 2 ? 0 : s.c + 1;
@@ -783,13 +898,14 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         // one whole block, even if it runs past the end of this sub-sequence
         const uint32_t c = b % 3;  // == s.c on a valid stream
         const int tdc = c ? 1 : 0, tac = 2 + tdc;
-        uint32_t win = peek32(w, s.p), sym, len;
+        uint32_t win = br.peek(), sym, len;
         if (!decode_symbol(T, win, tdc, sym, len)) err |= 8;
         uint32_t cat = sym & 15;
         if (sym >> 4) err |= 16;  // DC symbol with a run nibble: outside the contract
         uint32_t bits = cat ? (win << len) >> (32 - cat) : 0;
         int diff = extend(bits, cat);
         s.p += len + cat;
+        br.consume(w, len + cat);
         pred[c] += diff;             // DCDiff[c] += zz[0]   (MCU.cpp:107)
         blk[0] = (int16_t)pred[c];
         const bool keep_ac = sym != 0;  // quirk Q1: a DC "EOB" drops the block's AC terms (MCU.cpp:97-100)
@@ -799,16 +915,18 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         float Asum = fabsf(0.25f * (0x1.fffffep-2f * ((float)pred[c] * T.q00[tdc])));
         int nnz = 0;
         while (k < 64) {
-            win = peek32(w, s.p);
+            win = br.peek();
             if (!decode_symbol(T, win, tac, sym, len)) err |= 8;
             if (sym == 0) {
                 s.p += len;
+                br.consume(w, len);
                 break;
             }
             cat = sym & 15;
             const uint32_t run = sym >> 4;
             bits = cat ? (win << len) >> (32 - cat) : 0;
             s.p += len + cat;
+            br.consume(w, len + cat);
             k += run + 1;
             if (k > 64) {
                 err |= 32;  // run past the end of the block
