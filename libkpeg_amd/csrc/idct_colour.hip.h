@@ -69,6 +69,7 @@ struct IdctParams {
     uint32_t mcu_rows;    // MCU rows to produce
     uint32_t pitch;       // bytes per pixel row (width * 3)
     uint32_t tiles_w;     // ceil(mcus_w / TILE_MCUS)
+    uint32_t tiles_w_magic, tiles_w_shift;  // x / tiles_w == umulhi(x, magic) >> shift for x < 2^31 (host: div_magic)
     uint32_t ntiles;      // tiles_w * mcu_rows
     uint32_t* stats;      // [256] counters: [blockIdx & 255] += pixels sent to the exact path (may be null)
     uint32_t skip_exact;  // timing experiments only: count unsafe pixels but do not re-evaluate them
@@ -211,8 +212,15 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
 // |t - rint(t)| below this sends the G channel to the exact path (f32 error of t <= 3.7e-5)
 #define KPEG_G_DELTA 6.0e-5f
 
-__device__ __forceinline__ float block_ebound(float A, int nnz_ac)
+// Range guard folded into the bound: every fast sample satisfies |v| <= A (1 + 2^-20), so a block
+// whose A stays below the limit cannot leave the range the f32 colour arithmetic (chroma, |.| < 250)
+// or the queue's int16 fields (|.| < 32000) are proven for.  A block at or above the limit gets
+// E = +inf: all its samples take the reference-order path.
+#define KPEG_A_LIM_CHROMA 249.0f
+#define KPEG_A_LIM_LUMA 31000.0f
+__device__ __forceinline__ float block_ebound(float A, int nnz_ac, bool chroma)
 {
+    if (!(A < (chroma ? KPEG_A_LIM_CHROMA : KPEG_A_LIM_LUMA))) return __builtin_inff();
     return nnz_ac ? (KPEG_U * A) * ((float)nnz_ac + KPEG_KAPPA) : 0.0f;
 }
 
@@ -239,10 +247,11 @@ __global__ __launch_bounds__(256) void k_ebound(const int16_t* coef, uint32_t nb
             }
         }
     }
-    ebound[b] = block_ebound(A, n);
+    ebound[b] = block_ebound(A, n, t != 0);
 }
 
 typedef unsigned int uint3v __attribute__((ext_vector_type(3)));
+typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) uint4v;  // 16-byte view of uint32_t LDS words
 // int16 element k of a coefficient array kept as 32-bit words
 __device__ __forceinline__ int lds_coef(const uint32_t* w, int k)
 {
@@ -370,6 +379,11 @@ __device__ __forceinline__ void block_fast(const uint4 d, const LaneConst& lc, c
     column_idct8(a, lc.k[0], lc.k[1], lc.k[2], lc.k[3], lc.s, out);
 }
 
+__device__ __forceinline__ uint32_t tile_row(const IdctParams& p, uint32_t tile)
+{
+    return p.tiles_w == 1 ? tile : (__umulhi(tile, p.tiles_w_magic) >> p.tiles_w_shift);
+}
+
 __device__ __forceinline__ uint32_t pk_u8(float v, uint32_t sel, uint32_t old)
 {
     return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, old);  // saturating float -> byte `sel` of old
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     // MCU of this lane's group in a tile (groups beyond the image re-read the tile's first MCU;
     // their pixels are never stored)
     auto tile_mcu = [&](uint32_t tile) -> size_t {
-        const uint32_t trow = tile / p.tiles_w, tcol = tile - trow * p.tiles_w;
+        const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
         return (size_t)trow * p.mcus_w + m0 + ((uint32_t)grp < nm ? grp : 0);
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     // store.  Issued one iteration late, ahead of the next loads, so that waiting for a tile's
     // coefficients never waits for the stores that follow them in issue order.
     auto write_back = [&](uint32_t tile) {
-        const uint32_t trow = tile / p.tiles_w, tcol = tile - trow * p.tiles_w;
+        const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
         uint8_t* base = p.rgb + (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     uint32_t prev_tile = 0xFFFFFFFFu;
     uint32_t nq_total = 0;
     for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-        const uint32_t trow = tile / p.tiles_w, tcol = tile - trow * p.tiles_w;
+        const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
         const bool active = (uint32_t)grp < nm;
@@ -488,10 +502,10 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         {
             // keep the tile's coefficients at hand for the exact path: block (grp, c), row u
             // (plain uint32_t accesses on both sides: no type punning)
-            uint32_t* sc = s_coef + ((grp * 3) * 8 + u) * 4;
-            sc[0] = d0.x, sc[1] = d0.y, sc[2] = d0.z, sc[3] = d0.w;
-            sc[32] = d1.x, sc[33] = d1.y, sc[34] = d1.z, sc[35] = d1.w;
-            sc[64] = d2.x, sc[65] = d2.y, sc[66] = d2.z, sc[67] = d2.w;
+            uint4v* sc = reinterpret_cast<uint4v*>(s_coef) + (grp * 3) * 8 + u;
+            sc[0] = (uint4v){d0.x, d0.y, d0.z, d0.w};
+            sc[8] = (uint4v){d1.x, d1.y, d1.z, d1.w};
+            sc[16] = (uint4v){d2.x, d2.y, d2.z, d2.w};
         }
         float v[3][8];
         block_fast(d0, lc, &s_m[0][u * 8], 0, v[0]);
@@ -505,17 +519,15 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         // Nearly every wavefront has a few such pixels (true ties are structural: equal and opposite
         // (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5 exactly), so they are
         // queued straight from this loop with ballot compaction: no atomics, no second pass.
-        float amaxY = 0.f, amaxC = 0.f;
         uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
         uint32_t nq = 0;
         const uint32_t ent_lane = (uint32_t)grp | ((uint32_t)lane8 << 5);
+        const unsigned long long active_mask = __ballot(active);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
             const float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
             const float fy = fabsf(vy - ry) - thr0, fb = fabsf(vb - rb) - thr1, fr = fabsf(vr - rr) - thr2;
-            amaxY = fmaxf(amaxY, fabsf(ry));
-            amaxC = fmaxf(amaxC, fmaxf(fabsf(rb), fabsf(rr)));
             const float yf = ry + 128.0f;
             const float R = yf + floorf(rr * 1.402f);
             const float B = yf + floorf(rb * 1.772f);
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
 #ifndef KPEG_ABLATE_PUSH
             const bool push = active && key >= 0.0f;
-            const unsigned long long bal = __ballot(push);
+            const unsigned long long bal = __builtin_amdgcn_fcmpf(key, 0.0f, 3 /* FCMP_OGE */) & active_mask;
             if (bal) {  // wave-uniform
                 const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
                 if (push && slot < QUEUE_CAP) {
@@ -555,18 +567,6 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             dst[2] = make_uint2(pk[4], pk[5]);
         }
 
-        // operands outside the range the f32 colour arithmetic is proven for (never seen on real
-        // images): queue the lane's whole row, every component
-        if (__any(active && (amaxY >= KPEG_LUMA_LIM || amaxC >= KPEG_CHROMA_LIM))) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool push = active && (amaxY >= KPEG_LUMA_LIM || amaxC >= KPEG_CHROMA_LIM);
-                const unsigned long long bal = __ballot(push);
-                const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                if (push && slot < QUEUE_CAP) s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (7u << 11), 0u);
-                nq += __popcll(bal);
-            }
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 

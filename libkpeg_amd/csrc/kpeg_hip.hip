@@ -268,10 +268,22 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     if (ctx->idct_mode == 1) {
         p.tiles_w = 0;
         p.ntiles = 0;
+        p.tiles_w_magic = 0;
+        p.tiles_w_shift = 0;
         hipLaunchKernelGGL(k_idct_colour_exact, dim3(p.mcus_w * mcu_rows), dim3(64), 0, ctx->stream, p, qt);
     } else {
         p.tiles_w = (p.mcus_w + TILE_MCUS - 1) / TILE_MCUS;
         p.ntiles = p.tiles_w * mcu_rows;
+        {
+            // exact x / d for 0 <= x < 2^31, d >= 2: m = ceil(2^(32+s) / d) with s = ceil(log2 d) - 1 fits 32
+            // bits (2^s < d) and x * (m d - 2^(32+s)) < x d <= 2^(32+s) holds because 2^(s+1) >= d.
+            // d == 1 is handled in the kernel.
+            uint32_t d = p.tiles_w, lg = 0;
+            while ((1u << lg) < d) ++lg;
+            const uint32_t sft = lg ? lg - 1 : 0;
+            p.tiles_w_magic = d > 1 ? (uint32_t)((((uint64_t)1 << (32 + sft)) + d - 1) / d) : 0;
+            p.tiles_w_shift = sft;
+        }
         const uint32_t resident = (uint32_t)ctx->num_cus * K4_WAVES_PER_CU;  // one wavefront per workgroup
         const uint32_t grid = p.ntiles < resident ? p.ntiles : resident;
         hipLaunchKernelGGL(k_idct_colour_fast, dim3(grid), dim3(64), 0, ctx->stream, p, qt);

@@ -48,7 +48,8 @@ def test_kernel_error_constant_covers_the_derived_bound():
     assert 10.0 < k <= kk < k + 1.0, (k, kk)
     # K2 writes the same bound formula as block_ebound()
     ent = open(os.path.join(CSRC, "entropy.hip.h")).read()
-    assert "0x1.004p-24f * Asum) * ((float)nnz + %sf)" % ("%.1f" % kk) in ent
+    assert "(0x1.004p-24f * Asum) * ((float)nnz + %sf)" % ("%.1f" % kk) in ent
+    assert "Asum < (tdc ? 249.0f : 31000.0f)" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM_LUMA 31000.0f" in src
     assert "#define KPEG_U 0x1.004p-24f" in src
 
 
