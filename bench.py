@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--height", type=int, default=H8K, help="rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 dry run on a one-GPU box: gloo backend, every rank on cuda:0 (the driver's runs use RCCL, one GPU per rank)")
     ap.add_argument("--idct-mode", type=int, default=0, help="kpeg_hip_set_idct_mode (2 = timing experiment, wrong pixels)")
     ap.add_argument("--idct-only", action="store_true", help="time K4 alone on resident coefficients (BASELINE config 2 style)")
     args = ap.parse_args()
@@ -126,9 +128,15 @@ def main():
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path to measure")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if args.rehearse else "cuda"
 
     W, H = args.width, args.height
     mw, mh = W // 8, H // 8
@@ -190,7 +198,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.sync()  # deferred device status of the last step (raises on a corrupt stream)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -209,20 +217,29 @@ def main():
     # ---- gather of the stripes to rank 0 (the path's one exchange step), timed apart ----------
     gather = None
     if world > 1 and not args.no_gather:
-        glist = [torch.empty_like(d_rgb) for _ in range(world)] if rank == 0 else None
+        g_src = d_rgb.cpu() if args.rehearse else d_rgb
+        glist = [torch.empty_like(g_src) for _ in range(world)] if rank == 0 else None
         for _ in range(2):
-            dist.gather(d_rgb, glist, dst=0)
+            dist.gather(g_src, glist, dst=0)
         barrier()
         g0 = time.perf_counter()
         nrep = 5
         for _ in range(nrep):
-            dist.gather(d_rgb, glist, dst=0)
+            dist.gather(g_src, glist, dst=0)
         torch.cuda.synchronize()
         dist.barrier()
         gms = (time.perf_counter() - g0) / nrep * 1e3
-        t = torch.tensor([gms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([gms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gms = float(t.item())
+        if rank == 0 and os.environ.get("KPEG_BENCH_VERIFY"):
+            # rehearsal check: the gathered image equals the oracle's decode of the same virtual image
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import kpeg_testlib as T
+            full = torch.cat([g.cpu() for g in glist], 0).numpy()
+            want = np.concatenate([T.oracle_decode_rst(synth_jpeg(W, H, y0=r * H, restart_interval=mw), mw, 16)[0] for r in range(world)], 0)
+            assert np.array_equal(full, want), "gathered stripes differ from the oracle"
+            print("VERIFY_OK gathered %dx%d image equals the oracle" % (W, H * world), file=sys.stderr)
         gbytes = (world - 1) * d_rgb.numel()
         gather = {"ms": round(gms, 4), "GB/s_into_root": round(gbytes / gms / 1e6, 2), "bytes": gbytes,
                   "collective": "torch.distributed.gather over RCCL (grouped send/recv), RGB stripes -> rank 0"}

@@ -158,3 +158,40 @@ def test_full_size_8k_properties(ctx):
     st, want = T.oracle_decode(data, nthreads=16)
     assert st == T.DECODE_DONE
     assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+
+
+def test_decode_batch(ctx):
+    """kpeg_hip_decode_batch: independent images of one geometry and one set of tables."""
+    import ctypes
+    import libkpeg_amd as K
+    w, h, n = 128, 64, 5
+    datas = [T.synth_jpeg(w, h, seed=40 + i) for i in range(n)]
+    parsed = [K.host_parse(d) for d in datas]
+    frame = parsed[0][1]
+    scans = [np.ascontiguousarray(p[2]) for p in parsed]
+    outs = [np.empty((h, w, 3), np.uint8) for _ in range(n)]
+    sp = (ctypes.c_void_p * n)(*[s.ctypes.data for s in scans])
+    sl = (ctypes.c_size_t * n)(*[s.size for s in scans])
+    op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    rc = ctx.lib.kpeg_hip_decode_batch(ctx._h, n, ctypes.byref(frame), sp, sl, op)
+    assert rc == 0
+    for d, o in zip(datas, outs):
+        st, want = T.oracle_decode(d)
+        assert np.array_equal(o, want)
+
+
+def test_bench_multi_gpu_path_rehearsal():
+    """bench.py's N>1 path (per-rank stripe synthesis with restart markers, DRI parse, stripe decode at a
+    row offset, gather) as a 2-rank gloo rehearsal on this one GPU, verified against the oracle."""
+    import os, socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse",
+           "--width", "512", "--height", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, KPEG_BENCH_VERIFY="1"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "VERIFY_OK" in out.stderr
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["gather"]["bytes"] == 512 * 256 * 3
