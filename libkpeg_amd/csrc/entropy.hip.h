@@ -950,8 +950,12 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
 #pragma unroll
             for (int q = 0; q < 8; ++q) dst[q] = src[q];
             // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
-            a.ebound[gb] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff()
-                           : (nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f);
+            {
+                const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
+                // sign bit: all non-zero AC terms in the 2x2 corner (natural positions 1, 8, 9)
+                const bool corner = (touched & ~0x302ull) == 0;
+                a.ebound[gb] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : (corner ? -E : E);
+            }
             if (touched) {
                 uint4 z = make_uint4(0, 0, 0, 0);
                 uint4* b4 = reinterpret_cast<uint4*>(blk);

@@ -218,10 +218,15 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
 // E = +inf: all its samples take the reference-order path.
 #define KPEG_A_LIM_CHROMA 249.0f
 #define KPEG_A_LIM_LUMA 31000.0f
-__device__ __forceinline__ float block_ebound(float A, int nnz_ac, bool chroma)
+// The sign bit carries one more fact about the block: set = every non-zero AC coefficient sits at
+// (0,1), (1,0) or (1,1).  Those blocks produce nearly all true ties (equal and opposite (0,1)/(1,0)
+// terms cancel on the diagonal), and their reference-order sum has at most four terms, which the
+// lane that found the tie evaluates itself (exact_corner) instead of queueing the pixel.
+__device__ __forceinline__ float block_ebound(float A, int nnz_ac, bool chroma, bool corner_only)
 {
     if (!(A < (chroma ? KPEG_A_LIM_CHROMA : KPEG_A_LIM_LUMA))) return __builtin_inff();
-    return nnz_ac ? (KPEG_U * A) * ((float)nnz_ac + KPEG_KAPPA) : 0.0f;
+    const float E = nnz_ac ? (KPEG_U * A) * ((float)nnz_ac + KPEG_KAPPA) : 0.0f;
+    return corner_only ? -E : E;
 }
 
 // E for caller-supplied coefficients (kpeg_hip_idct_colour): one thread per block.
@@ -233,6 +238,7 @@ __global__ __launch_bounds__(256) void k_ebound(const int16_t* coef, uint32_t nb
     const uint4* src = reinterpret_cast<const uint4*>(coef + (size_t)b * 64);
     float A = 0.f;
     int n = 0;
+    bool corner = true;
     for (int r = 0; r < 8; ++r) {
         const uint4 d = src[r];
         const uint32_t w[4] = {d.x, d.y, d.z, d.w};
@@ -244,10 +250,11 @@ __global__ __launch_bounds__(256) void k_ebound(const int16_t* coef, uint32_t nb
             } else if (c != 0) {
                 A += fabsf((float)c * (0.25f * cc_of(r, i) * (float)qt.q[t][k]));
                 n++;
+                corner = corner && (k == 1 || k == 8 || k == 9);
             }
         }
     }
-    ebound[b] = block_ebound(A, n, t != 0);
+    ebound[b] = block_ebound(A, n, t != 0, corner);
 }
 
 typedef unsigned int uint3v __attribute__((ext_vector_type(3)));
@@ -389,6 +396,29 @@ __device__ __forceinline__ uint32_t pk_u8(float v, uint32_t sel, uint32_t old)
     return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, old);  // saturating float -> byte `sel` of old
 }
 
+// Reference-order value of one sample of a block whose non-zero coefficients all lie in the 2x2
+// low-frequency corner: MCU::computeIDCT's sum (MCU.cpp:184-198) restricted to the terms (0,0), (0,1),
+// (1,0), (1,1) in that order -- the others are zero and leave the float accumulator unchanged, as do
+// zero terms among these four (x + (+-0) == x), so no test is needed.  cos((2x+1)*0*pi/16) == 1.0 exactly.
+//   w0 / w1: LDS words holding coefficients (0,0),(0,1) / (1,0),(1,1); q..: the four quantisers as float;
+//   cx1 = cosT[x][1], cy1 = cosT[y][1].  Returns roundl(ic) as a float (the sample minus the level shift).
+__device__ __forceinline__ float exact_corner(uint32_t w0, uint32_t w1, float q00, float q01, float q10, float q11, double cx1,
+                                              double cy1)
+{
+    const float c0 = 0x1.6a09e6p-1f;  // (float)(1/sqrt 2)
+    const int F00 = (int)(short)(w0 & 0xFFFF) * (int)q00, F01 = ((int)w0 >> 16) * (int)q01;
+    const int F10 = (int)(short)(w1 & 0xFFFF) * (int)q10, F11 = ((int)w1 >> 16) * (int)q11;
+    const float fc00 = (c0 * c0) * (float)F00, fc01 = (c0 * 1.0f) * (float)F01, fc10 = (1.0f * c0) * (float)F10,
+                fc11 = (float)F11;
+    float sum = fc00;                                              // (float)(0.0 + fc00 * 1.0 * 1.0)
+    sum = (float)((double)sum + (double)fc01 * cy1);              // ((double)fc01 * 1.0) * cy1
+    sum = (float)((double)sum + (double)fc10 * cx1);              // ((double)fc10 * cx1) * 1.0
+    sum = (float)((double)sum + ((double)fc11 * cx1) * cy1);
+    const float ic = (float)(0.25 * (double)sum);
+    const float t = truncf(ic), fr = ic - t;
+    return t + (fr >= 0.5f ? 1.0f : 0.0f) - (fr <= -0.5f ? 1.0f : 0.0f);  // roundl: half away from zero
+}
+
 // One wavefront per workgroup: no workgroup barrier anywhere, every wave is an independent
 // worker walking its own tiles of 8 MCUs (64 x 8 pixels).  Small register footprint on purpose:
 // VALU issue on gfx950 needs >= 4 resident waves per SIMD to approach its rate
@@ -430,6 +460,9 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     // combine: out = own + mirror * s.  Even lane x: E_x - (-O_x) -> s = -1;
     // odd lane (pixel row 7-x): E_x - O_x = mirror(E_x) + own(-O_x) -> s = +1.
     lc.s = lane8 < 4 ? -1.0f : 1.0f;
+    const double cx1 = c_cos[lane8 * 8 + 1];  // cosT[pixel row][1] for exact_corner
+    const float qy00 = (float)qt.q[0][0], qy01 = (float)qt.q[0][1], qy10 = (float)qt.q[0][8], qy11 = (float)qt.q[0][9];
+    const float qc00 = (float)qt.q[1][0], qc01 = (float)qt.q[1][1], qc10 = (float)qt.q[1][8], qc11 = (float)qt.q[1][9];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -441,35 +474,23 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
         return (size_t)trow * p.mcus_w + m0 + ((uint32_t)grp < nm ? grp : 0);
     };
-    // coalesced write-back of a finished tile from LDS: 8 rows x nm*24 bytes, 12 bytes per lane and
-    // store.  Issued one iteration late, ahead of the next loads, so that waiting for a tile's
+    // Coalesced write-back of a finished tile from LDS: 8 rows x nm*24 bytes as 16-byte chunks
+    // (8 x 12 = 96 chunks: one per lane plus a second one on lanes 0..31; offsets fixed per lane).
+    // It is issued one iteration late, ahead of the next loads, so that waiting for a tile's
     // coefficients never waits for the stores that follow them in issue order.
+    const uint32_t wbA_r = tid / 12, wbA_k = tid - wbA_r * 12;
+    const uint32_t wbB_r = (tid + 64) / 12, wbB_k = (tid + 64) - wbB_r * 12;
+    const uint32_t wbA_lds = wbA_r * TILE_ROW_STRIDE + wbA_k * 16, wbA_g = wbA_r * p.pitch + wbA_k * 16;
+    const uint32_t wbB_lds = wbB_r * TILE_ROW_STRIDE + wbB_k * 16, wbB_g = wbB_r * p.pitch + wbB_k * 16;
+    const bool pitch16 = ((reinterpret_cast<uintptr_t>(p.rgb) | p.pitch) & 15) == 0;
     auto write_back = [&](uint32_t tile) {
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
         uint8_t* base = p.rgb + (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
-#if defined(KPEG_WB_NONE)
-        if (nm == 999) {
-#elif defined(KPEG_WB_X3)
-        if (nm == TILE_MCUS) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {  // 8 rows x 16 chunks of 12 bytes = 2 per lane
-                const int c = j * 64 + tid;
-                const int r = c >> 4, k = c & 15;
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(s_tile + r * TILE_ROW_STRIDE + k * 12);
-                uint32_t* dst = reinterpret_cast<uint32_t*>(base + (size_t)r * p.pitch + k * 12);
-                const uint32_t x0 = src[0], x1 = src[1], x2 = src[2];
-                asm volatile("global_store_dwordx3 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"((uint3v){x0, x1, x2}) : "memory");
-            }
-#else
-        if (nm == TILE_MCUS && ((reinterpret_cast<uintptr_t>(base) | p.pitch) & 15) == 0) {
-            for (int c = tid; c < 8 * (TILE_ROW_BYTES / 16); c += 64) {  // 8 rows x 12 chunks of 16 bytes
-                const int r = c / (TILE_ROW_BYTES / 16), k = c - r * (TILE_ROW_BYTES / 16);
-                const uint4 val = *reinterpret_cast<const uint4*>(s_tile + r * TILE_ROW_STRIDE + k * 16);
-                *reinterpret_cast<uint4*>(base + (size_t)r * p.pitch + k * 16) = val;
-            }
-#endif
+        if (nm == TILE_MCUS && pitch16) {
+            *reinterpret_cast<uint4*>(base + wbA_g) = *reinterpret_cast<const uint4*>(s_tile + wbA_lds);
+            if (tid < 32) *reinterpret_cast<uint4*>(base + wbB_g) = *reinterpret_cast<const uint4*>(s_tile + wbB_lds);
         } else {
             const uint32_t per_row = nm * 6;  // 4-byte pieces
             for (uint32_t c = tid; c < 8 * per_row; c += 64) {
@@ -511,7 +532,8 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         block_fast(d0, lc, &s_m[0][u * 8], 0, v[0]);
         block_fast(d1, lc, &s_m[1][u * 8], 1, v[1]);
         block_fast(d2, lc, &s_m[1][u * 8], 1, v[2]);
-        const float thr0 = 0.5f - e0, thr1 = 0.5f - e1, thr2 = 0.5f - e2;
+        const float thr0 = 0.5f - fabsf(e0), thr1 = 0.5f - fabsf(e1), thr2 = 0.5f - fabsf(e2);
+        const bool sp0 = __float_as_uint(e0) >> 31, sp1 = __float_as_uint(e1) >> 31, sp2 = __float_as_uint(e2) >> 31;
 
         // Level shift + colour for the 8 pixels of this lane's row.  Per pixel one float key says
         // whether the reference-order evaluation is needed (key >= 0): a fast value within its block's
@@ -526,8 +548,26 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
-            const float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
-            const float fy = fabsf(vy - ry) - thr0, fb = fabsf(vb - rb) - thr1, fr = fabsf(vr - rr) - thr2;
+            float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
+            float fy = fabsf(vy - ry) - thr0, fb = fabsf(vb - rb) - thr1, fr = fabsf(vr - rr) - thr2;
+            // a fast value within its block's bound of a rounding boundary (>= 0): corner-only blocks are
+            // settled here in reference order, the others stay flagged for the queue
+            if (__builtin_amdgcn_fcmpf(fmaxf(fy, fmaxf(fb, fr)), 0.0f, 3 /* OGE */) & active_mask) {  // wave-uniform
+                const double cy1 = c_cos[i * 8 + 1];
+                const uint32_t* blk = s_coef + grp * 96;
+                if (fy >= 0.0f && sp0) {
+                    ry = exact_corner(blk[0], blk[4], qy00, qy01, qy10, qy11, cx1, cy1);
+                    fy = -1.0f;
+                }
+                if (fb >= 0.0f && sp1) {
+                    rb = exact_corner(blk[32], blk[36], qc00, qc01, qc10, qc11, cx1, cy1);
+                    fb = -1.0f;
+                }
+                if (fr >= 0.0f && sp2) {
+                    rr = exact_corner(blk[64], blk[68], qc00, qc01, qc10, qc11, cx1, cy1);
+                    fr = -1.0f;
+                }
+            }
             const float yf = ry + 128.0f;
             const float R = yf + floorf(rr * 1.402f);
             const float B = yf + floorf(rb * 1.772f);
