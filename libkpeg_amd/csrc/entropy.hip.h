@@ -35,6 +35,12 @@
 
 namespace kpeg_dev {
 
+#ifndef KPEG_ABLATE_W
+#define KPEG_ABLATE_W 0   // timing experiments only (tools/variants.sh)
+#endif
+#ifndef KPEG_SYNC_STATS
+#define KPEG_SYNC_STATS 0
+#endif
 #ifndef KPEG_SUBSEQ_BITS
 #define KPEG_SUBSEQ_BITS 256
 #endif
@@ -495,6 +501,9 @@ struct RunResult {
     uint64_t exit_state;
     int nb;       // blocks started (DC symbols decoded)
     int dc[3];    // sum of DC differences of those blocks
+#if KPEG_SYNC_STATS
+    uint32_t iters;
+#endif
 };
 
 // Sync/count run: decode from `s` until the bit position reaches `pend`.
@@ -507,6 +516,9 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const BitSrc&
     br.init(w, s.p);
     uint32_t p = s.p, c = s.c, k = s.k;
     int nb = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+#if KPEG_SYNC_STATS
+    r.iters = 0;
+#endif
     // branch-free state machine: lanes of a wavefront sit at different points of their blocks
     while (p < pend) {
         const uint32_t win = br.peek();
@@ -531,6 +543,9 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const BitSrc&
         c = done ? (c == 2 ? 0u : c + 1) : c;
         p += used;
         br.consume(w, used);
+#if KPEG_SYNC_STATS
+        r.iters++;
+#endif
     }
     s.p = p;
     s.c = c;
@@ -585,6 +600,7 @@ struct SyncArgs {
     int4* wsum;        // [nwg_cap] per-workgroup totals of cnt
     uint32_t nwg_cap;
     int pass;
+    uint32_t* status;  // KPEG_SYNC_STATS builds only: words 8..13 collect loop counts
 };
 
 __device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -647,6 +663,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     int4 mycnt = make_int4(0, 0, 0, 0);
     bool dirty = false;
     uint64_t bentry = 0;
+#if KPEG_SYNC_STATS
+    uint32_t st_it = 0;
+#endif
     if (p == 0) {
         if (valid) {
             DecState s;
@@ -654,6 +673,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s.c = 0;
             s.k = 0;
             RunResult r = run_count(T, src, s, geo.pend);
+#if KPEG_SYNC_STATS
+            st_it = r.iters;
+#endif
             myX = r.exit_state;
             mycnt = make_int4(r.nb, r.dc[0], r.dc[1], r.dc[2]);
             dirty = geo.li != 0 && t > 0;
@@ -669,23 +691,47 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     s_X[t] = myX;
     const uint64_t x_at_entry = myX;
 
+#if KPEG_SYNC_STATS
+    uint32_t st_rounds = 0, st_jit = 0;
+    {
+        uint32_t m = st_it;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        if ((t & 63) == 0) { atomicAdd(&a.status[10], m); atomicAdd(&a.status[11], 1u); }
+    }
+#endif
     for (;;) {
         if (!__syncthreads_or(dirty)) break;  // also publishes s_X
+#if KPEG_SYNC_STATS
+        st_rounds++;
+#endif
         const uint64_t e = t == 0 ? bentry : s_X[t - 1];
         __syncthreads();
         bool changed = false;
         if (dirty) {
             RunResult r = run_count(T, src, unpack_state(e), geo.pend);
+#if KPEG_SYNC_STATS
+            st_jit = r.iters;
+#endif
             changed = r.exit_state != myX;
             myX = r.exit_state;
             mycnt = make_int4(r.nb, r.dc[0], r.dc[1], r.dc[2]);
             s_X[t] = myX;
         }
+#if KPEG_SYNC_STATS
+        {
+            uint32_t m = dirty ? st_jit : 0;
+            for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+            if ((t & 63) == 0) { atomicAdd(&a.status[12], m); atomicAdd(&a.status[13], m ? 1u : 0u); }
+        }
+#endif
         s_dirty[t + 1] = changed;
         __syncthreads();
         dirty = valid && t > 0 && geo.li != 0 && s_dirty[t];
     }
 
+#if KPEG_SYNC_STATS
+    if (t == 0) { atomicAdd(&a.status[8], st_rounds); atomicMax(&a.status[9], st_rounds); }
+#endif
     if (valid) {
         a.X[i] = myX;
         a.cnt[i] = mycnt;
@@ -801,6 +847,7 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
     __shared__ LdsTables T;
     __shared__ __attribute__((aligned(16))) int16_t s_blk[256 * WB_STRIDE];
     __shared__ int4 s_pre[256];
+    __shared__ uint4 s_flush[4][64];   // per wavefront: (block, error bound, owner lane) of blocks to write
     __shared__ uint32_t s_bits[STAGE_LDS];
     const uint32_t nsub = a.meta->nsub;
     if (blockIdx.x * 256u >= nsub) return;
@@ -838,9 +885,10 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         s_pre[threadIdx.x] = make_int4(w.x + incl.x - v.x, w.y + incl.y - v.y, w.z + incl.z - v.z, w.w + incl.w - v.w);
     }
     __syncthreads();
-    if (i >= nsub) return;
+    // lanes past the last sub-sequence stay: they help to write the others' blocks
     const uint32_t nseg = a.meta->nseg;
-    const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, i);
+    const uint32_t ii = min(i, nsub - 1);
+    const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, ii);
     const uint64_t* X = a.X;
 
     DecState s;
@@ -849,7 +897,7 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         s.c = 0;
         s.k = 0;
     } else {
-        s = unpack_state(X[i - 1]);
+        s = unpack_state(X[ii - 1]);
     }
     // block index and DC predictors at entry, relative to the segment start
     int4 pre;
@@ -857,7 +905,7 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
     if (a.prefix) {
         pre = make_int4(0, 0, 0, 0);
         if (g.li != 0) {
-            int4 pi = a.prefix[i], p0 = a.prefix[first];
+            int4 pi = a.prefix[ii], p0 = a.prefix[first];
             pre = make_int4(pi.x - p0.x, pi.y - p0.y, pi.z - p0.z, pi.w - p0.w);
         }
     } else {
@@ -868,105 +916,138 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
     const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
     const uint32_t blk_limit = seg_mcus * 3;       // blocks of this segment
     uint32_t b = (uint32_t)pre.x;                  // next block to start, within the segment
-    int pred[3] = {pre.y, pre.z, pre.w};
     const uint32_t seg_pend = a.seg_off[g.seg + 1] * 8;
 
+    const uint32_t lane = threadIdx.x & 63;
+    int16_t* wave_blk = s_blk + (threadIdx.x & ~63u) * WB_STRIDE;
+    uint4* fl_q = s_flush[threadIdx.x >> 6];
     BitReader br;
     br.init(w, s.p);
-    // a block that began in an earlier sub-sequence belongs to the lane that started it
-    while (s.k != 0 && s.p < seg_pend) {
-        uint32_t sym, len;
-        decode_symbol(T, br.peek(), 2 + (s.c ? 1 : 0), sym, len);
-        uint32_t used;
-        if (sym == 0) {
-            used = len;
-            s.k = 64;
-        } else {
-            used = len + (sym & 15);
-            s.k += (sym >> 4) + 1;
-        }
-        s.p += used;
-        br.consume(w, used);
-        if (s.k >= 64) {
-            s.k = 0;
-            s.c = s.c == 2 ? 0 : s.c + 1;
-        }
-    }
-
+    // One symbol per iteration for every lane (a flat state machine: the lanes of a wavefront sit at
+    // different points of different blocks, so nested per-block / per-symbol loops would make every
+    // lane wait for the longest block of each round).
+    //   own == false : finishing a block that began in an earlier sub-sequence; it belongs to the
+    //                  lane that started it, so its symbols are only stepped over
+    //   k == 0       : next symbol is a DC symbol (a block starts, if this sub-sequence still has bits)
     uint32_t err = 0;
-    while (s.p < g.pend && b < blk_limit) {
-        // one whole block, even if it runs past the end of this sub-sequence
-        const uint32_t c = b % 3;  // == s.c on a valid stream
-        const int tdc = c ? 1 : 0, tac = 2 + tdc;
-        uint32_t win = br.peek(), sym, len;
-        if (!decode_symbol(T, win, tdc, sym, len)) err |= 8;
-        uint32_t cat = sym & 15;
-        if (sym >> 4) err |= 16;  // DC symbol with a run nibble: outside the contract
-        uint32_t bits = cat ? (win << len) >> (32 - cat) : 0;
-        int diff = extend(bits, cat);
-        s.p += len + cat;
-        br.consume(w, len + cat);
-        pred[c] += diff;             // DCDiff[c] += zz[0]   (MCU.cpp:107)
-        blk[0] = (int16_t)pred[c];
-        const bool keep_ac = sym != 0;  // quirk Q1: a DC "EOB" drops the block's AC terms (MCU.cpp:97-100)
-        uint32_t k = 1;                 // coefficients placed so far + 1
-        uint64_t touched = 0;
-        // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
-        float Asum = fabsf(0.25f * (0x1.fffffep-2f * ((float)pred[c] * T.q00[tdc])));
-        int nnz = 0;
-        while (k < 64) {
-            win = br.peek();
-            if (!decode_symbol(T, win, tac, sym, len)) err |= 8;
-            if (sym == 0) {
-                s.p += len;
-                br.consume(w, len);
-                break;
-            }
-            cat = sym & 15;
-            const uint32_t run = sym >> 4;
-            bits = cat ? (win << len) >> (32 - cat) : 0;
-            s.p += len + cat;
-            br.consume(w, len + cat);
-            k += run + 1;
-            if (k > 64) {
-                err |= 32;  // run past the end of the block
-                break;
-            }
-            if (keep_ac) {
-                const int nat = T.zz[k - 1];
-                const int val = extend(bits, cat);
-                blk[nat] = (int16_t)val;
+    uint32_t p = s.p, k = s.k;
+    bool own = k == 0;
+    uint32_t cb = b % 3;                 // component of block b (== s.c at a block start of a valid stream)
+    uint32_t c = own ? cb : s.c;         // component whose tables are in use
+    int pred0 = pre.y, pred1 = pre.z, pred2 = pre.w;
+    bool keep_ac = false;
+    uint64_t touched = 0;
+    float Asum = 0.0f;   // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
+    int nnz = 0;
+    bool active = i < nsub;
+    for (;;) {
+        const bool indc = k == 0;
+        active = active && (indc ? (p < g.pend && b < blk_limit) : (own || p < seg_pend));
+        if (!__any(active)) break;   // wave-uniform: every lane stays for the cooperative write-out
+        const uint32_t tdc = c ? 1u : 0u;
+        bool done = false;
+        if (active) {
+        const uint32_t win = br.peek();
+        uint32_t sym, len;
+        const bool ok = decode_symbol(T, win, (int)((indc ? 0u : 2u) + tdc), sym, len);
+        if (!ok && own) err |= 8;
+        const uint32_t cat = sym & 15, run = sym >> 4;
+        const uint32_t bits = __builtin_amdgcn_ubfe(win << len, 32 - cat, cat);
+        const uint32_t half = (1u << cat) >> 1;
+        int val = (int)bits - (bits < half ? (int)((1u << cat) - 1u) : 0);   // EXTEND; 0 when cat == 0
+        const uint32_t used = len + cat;   // EOB and "no such code" have cat 0
+        p += used;
+        br.consume(w, used);
+        uint32_t nat = 0;
+        bool place;
+        if (indc) {
+            if (run) err |= 16;  // DC symbol with a run nibble: outside the contract
+            // DCDiff[c] += zz[0]   (MCU.cpp:107)
+            pred0 += c == 0 ? val : 0;
+            pred1 += c == 1 ? val : 0;
+            pred2 += c == 2 ? val : 0;
+            val = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
+            keep_ac = sym != 0;  // quirk Q1: a DC "EOB" drops the block's AC terms (MCU.cpp:97-100)
+            own = true;
+            touched = 0;
+            nnz = 0;
+            Asum = fabsf(0.25f * (0x1.fffffep-2f * ((float)val * T.q00[tdc])));
+            k = 1;               // coefficients placed so far + 1
+            place = true;
+            done = false;
+        } else {
+            const uint32_t kn = k + run + 1;
+            const bool eob = sym == 0;
+            const bool over = kn > 64;
+            if (over && !eob && own) err |= 32;  // run past the end of the block
+            place = !eob && !over && own && keep_ac;
+            nat = T.zz[(kn - 1) & 63];
+            done = eob || kn >= 64;
+            k = kn;
+            if (place) {
                 touched |= 1ull << nat;
                 Asum += fabsf((float)val * T.mscale[tdc][nat]);
                 nnz += val != 0;
             }
         }
-        if (s.p > seg_pend + 32) err |= 64;  // ran off the end of the data
-        // flush the 128-byte block, then clear what was touched
-        {
-            const uint32_t gb = (seg_mcu0 * 3 + b);
-            uint4* dst = reinterpret_cast<uint4*>(a.coef + (size_t)gb * 64);
-            const uint4* src = reinterpret_cast<const uint4*>(blk);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) dst[q] = src[q];
+#if KPEG_ABLATE_W != 3
+        if (place) blk[nat] = (int16_t)val;
+#endif
+        }
+        // Blocks completed in this iteration leave together: the owners queue (block, bound) and the
+        // wavefront writes the queued 128-byte blocks eight lanes to a block, so every store
+        // instruction fills whole cache lines (a lane flushing its own block alone would send eight
+        // 16-byte partial-line writes to L2: measured 2x the kernel's whole decode time).
+        const bool fl = done && own;   // done is false on lanes that sat this iteration out
+        const uint64_t flmask = __ballot(fl);
+        if (fl) {
+            if (p > seg_pend + 32) err |= 64;  // ran off the end of the data
+            const uint32_t gb = seg_mcu0 * 3 + b;
             // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
-            {
-                const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
-                // sign bit: all non-zero AC terms in the 2x2 corner (natural positions 1, 8, 9)
-                const bool corner = (touched & ~0x302ull) == 0;
-                a.ebound[gb] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : (corner ? -E : E);
-            }
-            if (touched) {
-                uint4 z = make_uint4(0, 0, 0, 0);
-                uint4* b4 = reinterpret_cast<uint4*>(blk);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) b4[q] = z;
+            const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
+            // sign bit: all non-zero AC terms in the 2x2 corner (natural positions 1, 8, 9)
+            const bool corner = (touched & ~0x302ull) == 0;
+            const float eb = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : (corner ? -E : E);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(flmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)flmask, 0));
+            fl_q[rank] = make_uint4(gb, __float_as_uint(eb), lane, 0);
+            b++;
+            cb = cb == 2 ? 0u : cb + 1;
+        }
+        if (flmask) {   // wave-uniform
+            const uint32_t nfl = (uint32_t)__popcll(flmask);
+            for (uint32_t j = lane >> 3; j < nfl; j += 8) {
+                const uint4 q = fl_q[j];
+                uint4* src = reinterpret_cast<uint4*>(wave_blk + q.z * WB_STRIDE) + (lane & 7);
+#if KPEG_ABLATE_W != 1 && KPEG_ABLATE_W != 2
+#if KPEG_ABLATE_W == 4
+                reinterpret_cast<uint4*>(a.coef + (size_t)(q.x & 4095) * 64)[lane & 7] = *src;
+                if ((lane & 7) == 0) a.ebound[q.x & 4095] = __uint_as_float(q.y);
+#elif KPEG_ABLATE_W == 5
+                if ((lane & 7) == 0) a.ebound[q.x] = __uint_as_float(q.y);
+#elif KPEG_ABLATE_W == 7
+                reinterpret_cast<uint4*>(a.coef + (size_t)q.x * 64)[lane & 7] = make_uint4(q.x, q.y, q.z, 1);
+#elif KPEG_ABLATE_W == 8
+                if ((lane & 7) == 0) a.ebound[q.x] = __uint_as_float(q.y + src->x);
+#elif KPEG_ABLATE_W == 6
+                reinterpret_cast<uint4*>(a.coef + (size_t)q.x * 64)[lane & 7] = *src;
+#else
+                reinterpret_cast<uint4*>(a.coef + (size_t)q.x * 64)[lane & 7] = *src;
+                if ((lane & 7) == 0) a.ebound[q.x] = __uint_as_float(q.y);
+#endif
+#endif
+#if KPEG_ABLATE_W != 2
+                *src = make_uint4(0, 0, 0, 0);
+#endif
             }
         }
-        b++;
+        if (done) {
+            k = 0;
+            c = cb;
+            own = true;
+        }
     }
     // the last sub-sequence of a segment must have produced the segment's last block
-    if (g.li + 1 == a.sub_base[g.seg + 1] - first && b < blk_limit) err |= 128;
+    if (i < nsub && g.li + 1 == a.sub_base[g.seg + 1] - first && b < blk_limit) err |= 128;
     if (err) atomicOr(&a.status[1], err);
 }
 
@@ -1061,6 +1142,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     sa.cnt = cnt;
     sa.wsum = (int4*)S->d_wsum;
     sa.nwg_cap = nwg_cap;
+    sa.status = L.d_status;
     const int npass = L.sync_passes > 0 ? L.sync_passes : SYNC_PASSES;
     for (int t = 0; t < npass; ++t) {
         sa.pass = t;
