@@ -10,18 +10,27 @@
 //   K0  unstuff   byte-parallel removal of the 00 after FF (reference rule incl. its tail
 //                 rule) and, with DRI, of the RSTn markers; prefix-sum compaction.  Output
 //                 is the bit string as big-endian 32-bit words + restart-segment offsets.
-//   K1  sync      one lane per sub-sequence of SUBSEQ_BITS bits: decode from a guessed
-//                 codeword boundary, then Jacobi rounds "re-decode from my predecessor's
-//                 exit state until nobody's exit state changes".  Huffman streams
-//                 re-synchronise after a few symbols, so a handful of rounds suffice; the
-//                 first sub-sequence of every restart segment starts from a known state.
-//                 Each run also counts the blocks it starts and sums their DC differences.
+//   K1  sync      one item per sub-sequence of SUBSEQ_BITS bits: decode from a guessed
+//                 codeword boundary, then rounds of "re-decode from my predecessor's exit
+//                 state" for exactly the items whose predecessor moved (a compacted work
+//                 list: Huffman streams re-synchronise after a few symbols, so the list
+//                 shrinks geometrically).  A workgroup also decodes the last WARM
+//                 sub-sequences of its predecessor, which gives it its own entry state
+//                 without waiting for the predecessor; pass 1 verifies that assumption against
+//                 the predecessor's real exit state and only a workgroup that guessed wrong
+//                 decodes again.  The first sub-sequence of every restart segment starts from
+//                 a known state.  Each run also counts the blocks it starts and sums their DC
+//                 differences.  Pass 0 clears the coefficient buffer in the background.
 //       scan      exclusive prefix sum of (blocks, dc[3]) over sub-sequences: absolute
 //                 block index and DC predictors at every sub-sequence entry.
 //   K2  write     one lane per sub-sequence decodes again from its true entry state and
-//                 writes whole 128-byte coefficient blocks (natural order, absolute DC,
-//                 quirk Q1 applied) -- the layout K4 reads.
-// Huffman look-up tables (9-bit first level + canonical long-code search) live in LDS.
+//                 scatters the non-zero coefficients into the cleared buffer (natural order,
+//                 absolute DC, quirk Q1 applied) -- the layout K4 reads -- plus K4's
+//                 per-block error bound.
+// The decode loops are bound by the instruction count of one symbol step (a wavefront runs
+// ~5 cycles per instruction on its own), so a Huffman table entry is a ready-made 32-bit
+// record (bits used, coefficient advance, flags) and the decoder's state is the LDS address
+// of the table in use.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -35,34 +44,62 @@
 
 namespace kpeg_dev {
 
-#ifndef KPEG_ABLATE_W
-#define KPEG_ABLATE_W 0   // timing experiments only (tools/variants.sh)
-#endif
 #ifndef KPEG_SYNC_STATS
-#define KPEG_SYNC_STATS 0
+#define KPEG_SYNC_STATS 0   // 1: loop counts into status words 8..13 (tools/sync_dbg.py)
 #endif
 #ifndef KPEG_SUBSEQ_BITS
-#define KPEG_SUBSEQ_BITS 256
+#define KPEG_SUBSEQ_BITS 128
 #endif
-constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable; 128, 256, 512 or 1024)
+#ifndef KPEG_SYNC_WG
+#define KPEG_SYNC_WG 512
+#endif
+constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable: 64, 128, 256, 512)
 constexpr int SUBSEQ_WORDS = SUBSEQ_BITS / 32;
-constexpr int LUT_BITS = 9;
-constexpr int SYNC_PASSES = 4;  // sync kernels enqueued per call: pass 0 + boundary passes (idle ones exit at once)
-constexpr int SYNC_WG = 256;    // sub-sequences per workgroup
+constexpr int SYNC_WG = KPEG_SYNC_WG;          // sub-sequences (and threads) per workgroup
+constexpr int SYNC_PASSES = 4;   // sync kernels enqueued per call: pass 0, the verifying pass 1, boundary passes (idle ones exit at once)
+constexpr int WARM_BITS = 1024;  // a workgroup decodes this much of its predecessor's tail to find its own entry state
+constexpr int WARM = (WARM_BITS + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
+constexpr int ITEMS = SYNC_WG + WARM;
+static_assert(SUBSEQ_BITS >= 64 && SUBSEQ_BITS % 32 == 0, "a symbol (<= 31 bits) must not jump over a whole sub-sequence");
 
-constexpr int LUT2_BITS = 16 - LUT_BITS;   // remaining bits of a long code
-constexpr int LUT2_SUBS = 12;             // second-level tables per Huffman table (canonical codes need few)
-constexpr uint16_t LUT_LONG = 0x8000;     // first-level entry: code longer than LUT_BITS, low bits = sub-table
-constexpr uint16_t LUT_SEARCH = 0xFFFF;   // ... no sub-table left: canonical search (never for real tables)
+constexpr int LUT_BITS = 9;
+constexpr int LUT2_BITS = 16 - LUT_BITS;  // remaining bits of a long code
+#ifndef KPEG_POOL_SUBS
+#define KPEG_POOL_SUBS 24
+#endif
+constexpr int POOL_SUBS = KPEG_POOL_SUBS;             // second-level tables shared by the four Huffman tables
+
+// Table entry: everything one symbol step needs, ready-made.
+//   [4:0] bits used (code + magnitude)   [9:5] code length   [13:10] magnitude bits (category)
+//   [14] entry of a DC table             [15] symbol 0x00 (DC: quirk Q1, AC: EOB) or no such code
+//   [22:16] coefficient advance: AC run + 1, EOB / no such code 64, DC 65 (>= 64 ends the table's turn)
+//   [23] no such code                    [24] DC symbol with a run nibble (outside the contract)
+//   [31] code longer than LUT_BITS: [15:0] = second-level table in the pool, E_SEARCH = none left
+constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_LONG = 1u << 31;
+constexpr uint32_t E_SEARCH = 0xFFFFu;
+
+__host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool isdc)
+{
+    const uint32_t cat = sym & 15, run = sym >> 4;
+    const uint32_t kadv = isdc ? 65u : (sym == 0 ? 64u : run + 1);
+    return (len + cat) | (len << 5) | (cat << 10) | (isdc ? E_ISDC : 0u) | (sym == 0 ? E_ZERO : 0u) | (kadv << 16) |
+           ((isdc && run) ? E_DCRUN : 0u);
+}
+// no such code: keep moving by 16 bits (only a speculative decode or a corrupt stream gets here;
+// the reference would never leave its bit loop, Decoder.cpp:704-748)
+__host__ __device__ inline uint32_t bad_entry(bool isdc)
+{
+    return 16u | (16u << 5) | (isdc ? E_ISDC : 0u) | E_ZERO | ((isdc ? 65u : 64u) << 16) | E_BAD;
+}
 
 struct EntropyTables {  // built on the host per frame, copied to the device when it changes
-    uint16_t lut[4][1 << LUT_BITS];  // [class*2+id]: (len << 8) | symbol; LUT_LONG | sub; 0 = no such code
-    uint16_t lut2[4][LUT2_SUBS][1 << LUT2_BITS];  // (len << 8) | symbol for codes of 10..16 bits; 0 = no such code
+    uint32_t lut[4][1 << LUT_BITS];          // [class*2+id], indexed by the next LUT_BITS bits
+    uint32_t pool[POOL_SUBS][1 << LUT2_BITS];  // second level: the LUT2_BITS bits after a long code's prefix
     int32_t maxcode[4][18];          // canonical: largest code of each length (-1 if none)
     int32_t valoff[4][18];           // symbol index of the first code of each length minus that code
     uint8_t symbols[4][256];
     uint8_t zz[64];                  // zig-zag -> natural
-    float mscale[2][64];             // 0.25 * cc[u][v] * Q[u][v], natural order ([.][0] unused): K4's input scale
+    float mscale_zz[2][64];          // 0.25 * cc[u][v] * Q[u][v] by zig-zag position ([.][0] unused): K4's input scale
     float q00[2];                    // Q[0][0] of both tables
 };
 
@@ -75,15 +112,18 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
         for (int k = 0; k < 64; ++k) {
             const int nat = KPEG_ZZ_TO_NATURAL[k], u = nat >> 3, v = nat & 7;
             const float cc = (u == 0 ? c0 : 1.0f) * (v == 0 ? c0 : 1.0f);
-            t->mscale[tq][nat] = 0.25f * cc * (float)f->qt[tq][k];
+            t->mscale_zz[tq][k] = 0.25f * cc * (float)f->qt[tq][k];
         }
         t->q00[tq] = (float)f->qt[tq][0];
     }
+    int nsub = 0;
     for (int cls = 0; cls < 2; ++cls)
         for (int id = 0; id < 2; ++id) {
             const kpeg_dht& h = f->dht[cls][id];
             const int ti = cls * 2 + id;
-            int code = 0, k = 0, nsub = 0;
+            const bool isdc = cls == 0;
+            for (int j = 0; j < (1 << LUT_BITS); ++j) t->lut[ti][j] = bad_entry(isdc);
+            int code = 0, k = 0;
             for (int len = 1; len <= 16; ++len) {
                 int cnt = h.counts[len - 1];
                 if (k + cnt > 256) return -1;
@@ -93,18 +133,25 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
                 for (int i = 0; i < cnt; ++i) {
                     uint8_t sym = h.symbols[k];
                     t->symbols[ti][k] = sym;
-                    const uint16_t e = (uint16_t)((len << 8) | sym);
+                    const uint32_t e = make_entry((uint32_t)len, sym, isdc);
                     if (len <= LUT_BITS) {
                         int first = code << (LUT_BITS - len);
                         for (int j = 0; j < (1 << (LUT_BITS - len)); ++j) t->lut[ti][first + j] = e;
                     } else {
                         const int prefix = code >> (len - LUT_BITS);
-                        uint16_t& l1 = t->lut[ti][prefix];
-                        if (l1 == 0) l1 = nsub < LUT2_SUBS ? (uint16_t)(LUT_LONG | nsub++) : LUT_SEARCH;
-                        if (l1 != LUT_SEARCH) {
-                            const int sub = l1 & 0x7FFF, rem = len - LUT_BITS;
+                        uint32_t& l1 = t->lut[ti][prefix];
+                        if (!(l1 & E_LONG)) {
+                            if (nsub < POOL_SUBS) {
+                                for (int j = 0; j < (1 << LUT2_BITS); ++j) t->pool[nsub][j] = bad_entry(isdc);
+                                l1 = E_LONG | (uint32_t)nsub++;
+                            } else {
+                                l1 = E_LONG | E_SEARCH;
+                            }
+                        }
+                        if ((l1 & 0xFFFFu) != E_SEARCH) {
+                            const int sub = (int)(l1 & 0xFFFFu), rem = len - LUT_BITS;
                             const int first = (code & ((1 << rem) - 1)) << (LUT2_BITS - rem);
-                            for (int j = 0; j < (1 << (LUT2_BITS - rem)); ++j) t->lut2[ti][sub][first + j] = e;
+                            for (int j = 0; j < (1 << (LUT2_BITS - rem)); ++j) t->pool[sub][first + j] = e;
                         }
                     }
                     code++;
@@ -121,7 +168,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t n_u;      // un-stuffed length in bytes
     uint32_t nseg;     // restart segments found (markers + 1)
     uint32_t nsub;     // total sub-sequences
-    uint32_t moved[SYNC_PASSES + 8];  // per pass: workgroups whose last exit state moved
+    uint32_t moved[SYNC_PASSES + 8];  // per pass >= 1: workgroups whose last exit state moved
     uint32_t total_blocks;
 };
 
@@ -129,7 +176,7 @@ struct EntropyScratch {
     void* d_u = nullptr;        size_t u_cap = 0;       // un-stuffed words
     void* d_part = nullptr;     size_t part_cap = 0;    // per-block partial sums of K0
     void* d_segoff = nullptr;   size_t seg_cap = 0;     // seg_off[S+1], sub_base[S+1]
-    void* d_state = nullptr;    size_t state_cap = 0;   // X[nsub] uint64, Xb[2][nwg] uint64, mv[2][nwg] uint8
+    void* d_state = nullptr;    size_t state_cap = 0;   // X[nsub], Xb[2][nwg], assumed[nwg] uint64
     void* d_cnt = nullptr;      size_t cnt_cap = 0;     // cnt[nsub] int4, prefix[nsub] int4
     void* d_wsum = nullptr;     size_t wsum_cap = 0;
     EntropyMeta* d_meta = nullptr;
@@ -378,55 +425,47 @@ __device__ __forceinline__ DecState unpack_state(uint64_t v)
     return s;
 }
 
+// LDS image of the tables.  The first-level tables stand in decode order
+//     DC comp 0, AC comp 0, DC comp 1, AC comp 1, DC comp 2, AC comp 2
+// (components 1 and 2 share their Huffman tables: two copies), so the byte offset tb of the table
+// in use is the decoder's whole (component, DC/AC) state: when a table's turn ends (a DC symbol, an
+// EOB, the 63rd AC coefficient) tb moves on by one table and wraps after AC comp 2.
+constexpr uint32_t LUT_BYTES = (1u << LUT_BITS) * 4;
 struct LdsTables {
-    uint16_t lut[4][1 << LUT_BITS];
-    uint16_t lut2[4][LUT2_SUBS][1 << LUT2_BITS];
+    uint32_t lut[6][1 << LUT_BITS];
+    uint32_t pool[POOL_SUBS][1 << LUT2_BITS];
     int32_t maxcode[4][18];
     int32_t valoff[4][18];
     uint8_t symbols[4][256];
     uint8_t zz[64];
-    float mscale[2][64];
+    float mscale_zz[2][64];
     float q00[2];
 };
+static_assert(sizeof(LdsTables) - sizeof(uint32_t) * 6 * (1 << LUT_BITS) == sizeof(EntropyTables) - sizeof(uint32_t) * 4 * (1 << LUT_BITS),
+              "layout after the first-level tables");
+
+__device__ __forceinline__ uint32_t slot_table(uint32_t slot) { return (slot & 1) * 2 + (slot >= 2 ? 1 : 0); }  // [class*2+id]
 
 __device__ __forceinline__ void load_tables(LdsTables* dst, const EntropyTables* src)
 {
-    static_assert(sizeof(LdsTables) == sizeof(EntropyTables), "layout");
-    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-    for (uint32_t i = threadIdx.x; i < sizeof(LdsTables) / 4; i += blockDim.x) d[i] = s[i];
+    uint32_t* l = &dst->lut[0][0];
+    for (uint32_t i = threadIdx.x; i < (6u << LUT_BITS); i += blockDim.x)
+        l[i] = src->lut[slot_table(i >> LUT_BITS)][i & ((1u << LUT_BITS) - 1)];
+    const uint32_t* s = &src->pool[0][0];
+    uint32_t* d = &dst->pool[0][0];
+    constexpr uint32_t n = (sizeof(EntropyTables) - sizeof(uint32_t) * 4 * (1 << LUT_BITS)) / 4;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
 }
 
-// The bit string as the decode loops see it: the workgroup's slice staged in LDS (a symbol costs
-// two LDS reads instead of two dependent global loads), anything beyond the slice from global memory.
-// LDS word j lives at j + j/SUBSEQ_WORDS: lanes start SUBSEQ_WORDS words apart, the padding spreads
-// them over the banks.
-constexpr int STAGE_WORDS = SYNC_WG * (SUBSEQ_BITS / 32);   // the workgroup's own sub-sequences
-constexpr int STAGE_MARGIN = 512;                           // words of run-over into the next workgroup
-constexpr int STAGE_TOTAL = STAGE_WORDS + STAGE_MARGIN;
-constexpr int STAGE_LDS = STAGE_TOTAL + STAGE_TOTAL / SUBSEQ_WORDS + 2;
-__device__ __forceinline__ uint32_t stage_idx(uint32_t j) { return j + j / SUBSEQ_WORDS; }
-
-struct BitSrc {
-    const uint32_t* __restrict__ g;   // whole un-stuffed string
-    const uint32_t* lds;              // staged slice
-    uint32_t w0;                      // first staged word
-    uint32_t nw;                      // staged words
-};
-
-__device__ __forceinline__ void stage_bits(uint32_t* lds, const uint32_t* __restrict__ g, uint32_t w0, uint32_t nw)
+// The bit string as the decode loops see it: the workgroup's slice staged in LDS.  Every position
+// a lane can reach lies inside the slice: a run ends at most one symbol (< 32 bits) past its own
+// sub-sequence and K2 finishes at most one block (< 63 * 31 bits) past it, plus 96 bits of
+// look-ahead; STAGE_MARGIN words cover that.  Only a corrupt stream can run further (it reads
+// whatever LDS holds there; the result is flagged as an error elsewhere).
+constexpr int STAGE_MARGIN = 96;
+__device__ __forceinline__ void stage_bits(uint32_t* lds, uint32_t cap, const uint32_t* __restrict__ g, uint32_t w0, uint32_t nw)
 {
-    for (uint32_t j = threadIdx.x; j < nw; j += blockDim.x) lds[stage_idx(j)] = g[w0 + j];
-}
-
-// Word i of the bit string for the decode loops.  Every position a lane can reach lies inside its
-// workgroup's staged slice: a run starts at most one symbol (< 32 bits) before its own sub-sequence
-// and K2 finishes at most one block (< 1728 bits, STAGE_MARGIN is 16384) past it.  Only a corrupt
-// stream can run further; its reads are clamped (the result is flagged as an error elsewhere).
-__device__ __forceinline__ uint32_t src_word(const BitSrc& b, uint32_t i)
-{
-    const uint32_t j = min(i - b.w0, b.nw - 1);
-    return b.lds[stage_idx(j)];
+    for (uint32_t j = threadIdx.x; j < cap; j += blockDim.x) lds[j] = j < nw ? g[w0 + j] : 0u;
 }
 
 // Sequential reader: the next >= 32 bits sit MSB-aligned in a 64-bit register, so a symbol's
@@ -434,127 +473,124 @@ __device__ __forceinline__ uint32_t src_word(const BitSrc& b, uint32_t i)
 // refill ahead.
 struct BitReader {
     uint64_t buf;
-    uint32_t have;   // valid bits in buf, >= 32 between symbols
-    uint32_t wi;     // index of the word after `nextw`
+    uint32_t have;        // valid bits in buf, > 32 between symbols
+    const uint32_t* wp;   // word after `nextw` in the staged slice
     uint32_t nextw;
 
-    __device__ __forceinline__ void init(const BitSrc& b, uint32_t p)
+    __device__ __forceinline__ void init(const uint32_t* lds, uint32_t w0, uint32_t p)
     {
-        const uint32_t i = p >> 5, o = p & 31;
-        buf = (((uint64_t)src_word(b, i) << 32) | src_word(b, i + 1)) << o;
+        const uint32_t o = p & 31;
+        wp = lds + ((p >> 5) - w0);
+        buf = (((uint64_t)wp[0] << 32) | wp[1]) << o;
         have = 64 - o;
-        nextw = src_word(b, i + 2);
-        wi = i + 3;
+        nextw = wp[2];
+        wp += 3;
     }
     __device__ __forceinline__ uint32_t peek() const { return (uint32_t)(buf >> 32); }
-    __device__ __forceinline__ void consume(const BitSrc& b, uint32_t n)   // n <= 31
+    __device__ __forceinline__ void consume(uint32_t n)   // n <= 31
     {
         buf <<= n;
         have -= n;
         if (have <= 32) {
             buf |= (uint64_t)nextw << (32 - have);
             have += 32;
-            nextw = src_word(b, wi);
-            wi++;
+            nextw = *wp++;
         }
     }
 };
 
-// Decodes one symbol at state s.  Returns false when the code is not in the table (the
-// reference would never leave its bit loop, Decoder.cpp:704-748).
-// On return: sym, total bits consumed (code + magnitude bits), value bits in `vbits`.
-__device__ __forceinline__ bool decode_symbol(const LdsTables& T, uint32_t win, int ti, uint32_t& sym, uint32_t& len)
+// canonical search, for tables with more long-code prefixes than the pool holds (never for real tables)
+__device__ inline uint32_t search_entry(const LdsTables& T, uint32_t tb, uint32_t win)
 {
-    uint32_t e = T.lut[ti][win >> (32 - LUT_BITS)];
-    if (e & LUT_LONG) {  // 10..16-bit code: one more table read
-        if (e != LUT_SEARCH) {
-            e = T.lut2[ti][e & 0x7FFF][(win >> (32 - 16)) & ((1 << LUT2_BITS) - 1)];
-        } else {
-            e = 0;
-            for (int l = LUT_BITS + 1; l <= 16; ++l) {
-                int code = (int)(win >> (32 - l));
-                if (code <= T.maxcode[ti][l]) {
-                    e = ((uint32_t)l << 8) | T.symbols[ti][(T.valoff[ti][l] + code) & 255];
-                    break;
-                }
-            }
-        }
+    const uint32_t slot = tb / LUT_BYTES, ti = slot_table(slot);
+    const bool isdc = !(slot & 1);
+    for (int l = LUT_BITS + 1; l <= 16; ++l) {
+        const int code = (int)(win >> (32 - l));
+        if (code <= T.maxcode[ti][l]) return make_entry((uint32_t)l, T.symbols[ti][(T.valoff[ti][l] + code) & 255], isdc);
     }
-    sym = e & 0xFF;
-    len = e >> 8;
-    if (e == 0) {
-        len = 16;  // no such code: keep moving (only a speculative decode or a corrupt stream gets here)
-        return false;
-    }
-    return true;
+    return bad_entry(isdc);
 }
 
-// JPEG EXTEND (bitStringtoValue, Image.cpp:285-302)
-__device__ __forceinline__ int extend(uint32_t bits, uint32_t cat)
+// The entry of the symbol at the head of `win` (the next 32 bits), table at byte offset tb.
+__device__ __forceinline__ uint32_t lut_entry(const LdsTables& T, uint32_t tb, uint32_t win)
 {
-    if (cat == 0) return 0;
-    int v = (int)bits;
-    return (bits >> (cat - 1)) ? v : v - (int)((1u << cat) - 1u);
+    const char* base = reinterpret_cast<const char*>(&T.lut[0][0]);
+    uint32_t e = *reinterpret_cast<const uint32_t*>(base + tb + ((win >> (32 - LUT_BITS)) << 2));
+    if (e & E_LONG) {  // 10..16-bit code: one more table read
+        const uint32_t sub = e & 0xFFFFu;
+        e = sub != E_SEARCH ? T.pool[sub][(win >> (32 - 16)) & ((1u << LUT2_BITS) - 1)] : search_entry(T, tb, win);
+    }
+    return e;
 }
+
+// JPEG EXTEND (bitStringtoValue, Image.cpp:285-302) of the `cat` bits that follow a `len`-bit code
+__device__ __forceinline__ int extend_win(uint32_t win, uint32_t len, uint32_t cat)
+{
+    const uint32_t t = win << len;  // magnitude bits at the top
+    const uint32_t bits = __builtin_amdgcn_ubfe(t, 32 - cat, cat);   // 0 when cat == 0
+    const int ones = (int)((1u << cat) - 1u);
+    return (int)bits - ((int)t < 0 ? 0 : ones);
+}
+
+__device__ __forceinline__ uint32_t state_table(const DecState& s) { return (s.c * 2 + (s.k != 0 ? 1u : 0u)) * LUT_BYTES; }
 
 struct RunResult {
     uint64_t exit_state;
-    int nb;       // blocks started (DC symbols decoded)
-    int dc[3];    // sum of DC differences of those blocks
+    int4 cnt;     // blocks started (DC symbols decoded), sums of their DC differences per component
 #if KPEG_SYNC_STATS
     uint32_t iters;
 #endif
 };
 
 // Sync/count run: decode from `s` until the bit position reaches `pend`.
-__device__ __forceinline__ RunResult run_count(const LdsTables& T, const BitSrc& w, DecState s, uint32_t pend)
+__device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend)
 {
-    RunResult r;
-    r.nb = 0;
-    r.dc[0] = r.dc[1] = r.dc[2] = 0;
     BitReader br;
-    br.init(w, s.p);
-    uint32_t p = s.p, c = s.c, k = s.k;
-    int nb = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    br.init(bits, w0, s.p);
+    uint32_t p = s.p, k = s.k, tb = state_table(s);
+    const uint32_t cfirst = s.k == 0 ? s.c : (s.c == 2 ? 0u : s.c + 1);  // component of the first block started here
+    // DC sums rotate with the blocks: the current block's component adds into the slot that moves to the back
+    int s0 = 0, s1 = 0, s2 = 0;
+    uint32_t nb = 0;
 #if KPEG_SYNC_STATS
-    r.iters = 0;
+    uint32_t iters = 0;
 #endif
-    // branch-free state machine: lanes of a wavefront sit at different points of their blocks
     while (p < pend) {
         const uint32_t win = br.peek();
-        const uint32_t isac = k != 0;
-        uint32_t sym, len;
-        decode_symbol(T, win, (int)(isac * 2 + (c != 0)), sym, len);
-        const uint32_t cat = sym & 15, run = sym >> 4;   // EOB (symbol 0) has cat 0: it consumes len bits
-        const uint32_t used = len + cat;
-        // DC difference (EXTEND), only counted when this symbol is a DC symbol
-        const uint32_t bits = __builtin_amdgcn_ubfe(win << len, 32 - cat, cat);
-        const uint32_t half = (1u << cat) >> 1;
-        const int d = (int)bits - (bits < half ? (int)((1u << cat) - 1u) : 0);
-        const int dd = isac ? 0 : d;
-        nb += (int)(isac ^ 1u);
-        dc0 += c == 0 ? dd : 0;
-        dc1 += c == 1 ? dd : 0;
-        dc2 += c == 2 ? dd : 0;
-        uint32_t kn = isac ? k + run + 1 : 1u;
-        kn = (isac && sym == 0) ? 64u : kn;       // EOB
-        const bool done = kn >= 64;                // block complete (EOB, or ACCodesCount == 63, Decoder.cpp:759)
-        k = done ? 0u : kn;
-        c = done ? (c == 2 ? 0u : c + 1) : c;
-        p += used;
-        br.consume(w, used);
+        const uint32_t e = lut_entry(T, tb, win);
+        const uint32_t kraw = k + ((e >> 16) & 127);
+        const bool adv = kraw >= 64;   // this table's turn ends: DC symbol, EOB, 63rd coefficient (Decoder.cpp:759)
+        if (e & E_ISDC) {
+            const int n = s0 + extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
+            s0 = s1;
+            s1 = s2;
+            s2 = n;
+            nb++;
+        }
+        k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
+        tb += adv ? LUT_BYTES : 0u;
+        tb = tb == 6 * LUT_BYTES ? 0u : tb;
+        p += e & 31;
+        br.consume(e & 31);
 #if KPEG_SYNC_STATS
-        r.iters++;
+        iters++;
 #endif
     }
-    s.p = p;
-    s.c = c;
-    s.k = k;
-    r.nb = nb;
-    r.dc[0] = dc0;
-    r.dc[1] = dc1;
-    r.dc[2] = dc2;
-    r.exit_state = pack_state(s);
+    RunResult r;
+    // slot j holds component (cfirst + nb + j) mod 3
+    const uint32_t rot = (cfirst + nb) % 3;
+    r.cnt.x = (int)nb;
+    r.cnt.y = rot == 0 ? s0 : (rot == 1 ? s2 : s1);
+    r.cnt.z = rot == 0 ? s1 : (rot == 1 ? s0 : s2);
+    r.cnt.w = rot == 0 ? s2 : (rot == 1 ? s1 : s0);
+    DecState x;
+    x.p = p;
+    x.c = tb / (2 * LUT_BYTES);
+    x.k = k;
+    r.exit_state = pack_state(x);
+#if KPEG_SYNC_STATS
+    r.iters = iters;
+#endif
     return r;
 }
 
@@ -587,157 +623,190 @@ __device__ __forceinline__ SubGeom sub_geom(const uint32_t* __restrict__ seg_off
     return g;
 }
 
+__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ------------------------------------------------------------------------------------------
+// K1: sync
 struct SyncArgs {
     const uint32_t* u;
     const uint32_t* seg_off;
     const uint32_t* sub_base;
     EntropyMeta* meta;
     const EntropyTables* tabs;
-    uint64_t* X;       // [nsub_cap] exit state of every sub-sequence (written by its workgroup only)
-    uint64_t* Xb;      // [2][nwg_cap] exit state of each workgroup's last sub-sequence, ping-pong by pass
-    uint8_t* mv;       // [2][nwg_cap] "my last exit state moved in this pass"
-    int4* cnt;         // [nsub_cap] (blocks started, dc sums) of the run that produced X
-    int4* wsum;        // [nwg_cap] per-workgroup totals of cnt
+    uint64_t* X;        // [nsub_cap] exit state of every sub-sequence (written by its workgroup only)
+    uint64_t* Xb;       // [2][nwg_cap] exit state of each workgroup's last sub-sequence, ping-pong by pass
+    uint64_t* assumed;  // [nwg_cap] entry state each workgroup last decoded from (X_NONE: known, first of a segment)
+    int4* cnt;          // [nsub_cap] (blocks started, dc sums) of the run that produced X
+    int4* wsum;         // [nwg_cap] per-workgroup totals of cnt
+    uint4* coef16;      // pass 0 clears the coefficient buffer, a slice per workgroup, behind its decode
+    uint64_t coef_n16;
     uint32_t nwg_cap;
     int pass;
-    uint32_t* status;  // KPEG_SYNC_STATS builds only: words 8..13 collect loop counts
+    uint32_t* status;   // KPEG_SYNC_STATS builds only: words 8..13 collect loop counts
 };
+constexpr uint64_t X_NONE = ~0ull;
 
-__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// Appends v to list[] for every lane that wants to; call with the whole wavefront converged.
+__device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list, uint32_t* counter)
+{
+    const uint64_t m = __ballot(want);
+    if (m == 0) return;
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, 0);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    if (want) list[base + rank] = (uint16_t)v;
+}
 
-// Pass 0: every sub-sequence decodes from a guessed boundary (its own first bit, DC of
-// component 0), then the workgroup iterates "re-decode from my predecessor's exit state
-// where that moved" until nothing moves (Jacobi rounds, LDS only).  The first sub-sequence
-// of a restart segment starts from a known state; the first one of a workgroup cannot be
-// checked inside the workgroup.
-// Pass p >= 1: the first sub-sequence of each workgroup whose predecessor workgroup moved in
-// pass p-1 re-decodes from that workgroup's exit state and the change, if any, ripples on.
+// Items of a workgroup: [0, wu) the last wu sub-sequences of its predecessor (warm-up, pass 0 only),
+// [wu, nit) its own.  s_X[j] is the entry state of item j, i.e. the exit state of item j - 1.
+// Pass 0: every item decodes from a guessed boundary (its own first bit, DC of component 0; the
+//   first sub-sequence of a restart segment from its known state), then rounds re-decode exactly the
+//   items whose predecessor's exit state moved, until none moves (work list in LDS).  Item 0's
+//   guess cannot be checked here: the warm-up distance makes it irrelevant for the own items unless
+//   the stream needs more than WARM_BITS to re-synchronise.
+// Pass p >= 1: a workgroup whose assumed entry state differs from its predecessor's real exit
+//   state re-decodes from that state and the change ripples on.
 __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 {
     __shared__ LdsTables T;
-    __shared__ uint64_t s_X[SYNC_WG];
-    __shared__ uint8_t s_dirty[SYNC_WG + 1];
+    __shared__ uint64_t s_X[ITEMS + 1];
+    __shared__ uint32_t s_geo[ITEMS + 1];   // pend | first-of-its-segment << 31
+    __shared__ int4 s_cnt[SYNC_WG];
+    __shared__ uint16_t s_list[2][ITEMS];
+    __shared__ uint32_t s_n[3];
     __shared__ int4 s_red[SYNC_WG / 64];
-    __shared__ uint32_t s_bits[STAGE_LDS];
-    const uint32_t nsub = a.meta->nsub;
+    constexpr uint32_t STAGE_CAP = ITEMS * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
+    __shared__ uint32_t s_bits[STAGE_CAP];
     const int p = a.pass;
     const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t nsub = a.meta->nsub;
     const uint32_t i0 = g * SYNC_WG;
     if (i0 >= nsub) return;
     if (p >= 2 && a.meta->moved[p - 1] == 0) return;  // converged
-    const uint8_t* mv_prev = a.mv + (size_t)((p & 1) ^ 1) * a.nwg_cap;
-    uint8_t* mv_cur = a.mv + (size_t)(p & 1) * a.nwg_cap;
     const uint64_t* Xb_prev = a.Xb + (size_t)((p & 1) ^ 1) * a.nwg_cap;
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
-    if (p >= 1 && (g == 0 || mv_prev[g - 1] == 0)) {
-        // nothing upstream moved: my states stand
-        if (t == 0) {
-            mv_cur[g] = 0;
-            Xb_cur[g] = Xb_prev[g];
+    if (p >= 1) {
+        const uint64_t as = a.assumed[g];
+        if (g == 0 || as == X_NONE || as == Xb_prev[g - 1]) {
+            // the state this workgroup decoded from stands, and so do its results
+            if (t == 0) Xb_cur[g] = Xb_prev[g];
+            return;
         }
-        return;
     }
     load_tables(&T, a.tabs);
-    const uint32_t i = i0 + t;
-    const bool valid = i < nsub;
     const uint32_t nseg = a.meta->nseg;
-    SubGeom geo;
-    geo.seg = 0;
-    geo.li = 0;
-    geo.pstart = geo.pend = 0;
-    if (valid) geo = sub_geom(a.seg_off, a.sub_base, nseg, i);
+    const uint32_t nown = min((uint32_t)SYNC_WG, nsub - i0);
+    const uint32_t wu = p == 0 ? min((uint32_t)WARM, i0) : 0u;
+    const uint32_t ibase = i0 - wu, nit = wu + nown;
     // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
-    BitSrc src;
+    const uint32_t w0 = sub_geom(a.seg_off, a.sub_base, nseg, ibase).pstart >> 5;
     {
-        const SubGeom g0 = sub_geom(a.seg_off, a.sub_base, nseg, i0);
-        src.g = a.u;
-        src.lds = s_bits;
-        src.w0 = g0.pstart >> 5;
         const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
-        src.nw = min((uint32_t)STAGE_TOTAL, total_words > src.w0 ? total_words - src.w0 : 0u);
-        stage_bits(s_bits, a.u, src.w0, src.nw);
+        stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
+    if (t < 3) s_n[t] = 0;
     __syncthreads();
 
-    uint64_t myX = 0;
-    int4 mycnt = make_int4(0, 0, 0, 0);
-    bool dirty = false;
-    uint64_t bentry = 0;
 #if KPEG_SYNC_STATS
-    uint32_t st_it = 0;
+    uint32_t st_runs = 0, st_iters = 0, st_rounds = 0;
 #endif
     if (p == 0) {
-        if (valid) {
-            DecState s;
-            s.p = geo.pstart;
-            s.c = 0;
-            s.k = 0;
-            RunResult r = run_count(T, src, s, geo.pend);
+        for (uint32_t jb = 0; jb < nit; jb += SYNC_WG) {
+            const uint32_t j = jb + t;
+            bool want = false;
+            if (j < nit) {
+                const SubGeom geo = sub_geom(a.seg_off, a.sub_base, nseg, ibase + j);
+                s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
+                DecState s;
+                s.p = geo.pstart;
+                s.c = 0;
+                s.k = 0;
+                const RunResult r = run_count(T, s_bits, w0, s, geo.pend);
 #if KPEG_SYNC_STATS
-            st_it = r.iters;
+                st_runs++;
+                st_iters += r.iters;
 #endif
-            myX = r.exit_state;
-            mycnt = make_int4(r.nb, r.dc[0], r.dc[1], r.dc[2]);
-            dirty = geo.li != 0 && t > 0;
+                s_X[j + 1] = r.exit_state;
+                if (j >= wu) s_cnt[j - wu] = r.cnt;
+                want = geo.li != 0 && j > 0;
+            }
+            push_item(want, j, s_list[0], &s_n[0]);
         }
     } else {
-        if (valid) {
-            myX = a.X[i];
-            mycnt = a.cnt[i];
-            dirty = t == 0 && geo.li != 0;
+        for (uint32_t j = t; j < nit; j += SYNC_WG) {
+            const SubGeom geo = sub_geom(a.seg_off, a.sub_base, nseg, ibase + j);
+            s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
+            s_X[j + 1] = a.X[i0 + j];
+            s_cnt[j] = a.cnt[i0 + j];
         }
-        bentry = Xb_prev[g - 1];
+        if (t == 0) {
+            s_X[0] = Xb_prev[g - 1];
+            s_list[0][0] = 0;
+            s_n[0] = 1;
+        }
     }
-    s_X[t] = myX;
-    const uint64_t x_at_entry = myX;
 
-#if KPEG_SYNC_STATS
-    uint32_t st_rounds = 0, st_jit = 0;
-    {
-        uint32_t m = st_it;
-        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-        if ((t & 63) == 0) { atomicAdd(&a.status[10], m); atomicAdd(&a.status[11], 1u); }
+#ifndef KPEG_ABLATE_NOZERO
+    // pass 0 clears the coefficient buffer behind the rounds below, which only touch LDS
+    if (p == 0) {
+        const uint32_t nwg = (nsub + SYNC_WG - 1) / SYNC_WG;   // the workgroups that get here
+        const uint64_t per = (a.coef_n16 + nwg - 1) / nwg;
+        const uint64_t b0 = (uint64_t)g * per, b1 = min(a.coef_n16, b0 + per);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint64_t q = b0 + t; q < b1; q += SYNC_WG) a.coef16[q] = z;
     }
 #endif
-    for (;;) {
-        if (!__syncthreads_or(dirty)) break;  // also publishes s_X
+    for (uint32_t round = 0;; ++round) {
+        __syncthreads();
+        const uint32_t n = s_n[round % 3];
+        if (n == 0) break;
+        if (t == 0) s_n[(round + 2) % 3] = 0;
+        const uint16_t* lc = s_list[round & 1];
+        uint16_t* ln = s_list[(round & 1) ^ 1];
+        uint32_t* cn = &s_n[(round + 1) % 3];
 #if KPEG_SYNC_STATS
         st_rounds++;
 #endif
-        const uint64_t e = t == 0 ? bentry : s_X[t - 1];
-        __syncthreads();
-        bool changed = false;
-        if (dirty) {
-            RunResult r = run_count(T, src, unpack_state(e), geo.pend);
+        for (uint32_t qb = 0; qb < n; qb += SYNC_WG) {
+            const uint32_t q = qb + t;
+            bool want = false;
+            uint32_t j = 0;
+            if (q < n) {
+                j = lc[q];
+                // a predecessor re-decoded in this same round may or may not have stored its new
+                // exit state yet: either value is a valid start, and if it moved this item is on
+                // the next list again
+                const RunResult r = run_count(T, s_bits, w0, unpack_state(s_X[j]), s_geo[j] & 0x7FFFFFFFu);
 #if KPEG_SYNC_STATS
-            st_jit = r.iters;
+                st_runs++;
+                st_iters += r.iters;
 #endif
-            changed = r.exit_state != myX;
-            myX = r.exit_state;
-            mycnt = make_int4(r.nb, r.dc[0], r.dc[1], r.dc[2]);
-            s_X[t] = myX;
+                const bool changed = r.exit_state != s_X[j + 1];
+                s_X[j + 1] = r.exit_state;
+                if (j >= wu) s_cnt[j - wu] = r.cnt;
+                want = changed && j + 1 < nit && !(s_geo[j + 1] >> 31);
+            }
+            push_item(want, j + 1, ln, cn);
         }
-#if KPEG_SYNC_STATS
-        {
-            uint32_t m = dirty ? st_jit : 0;
-            for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-            if ((t & 63) == 0) { atomicAdd(&a.status[12], m); atomicAdd(&a.status[13], m ? 1u : 0u); }
-        }
-#endif
-        s_dirty[t + 1] = changed;
-        __syncthreads();
-        dirty = valid && t > 0 && geo.li != 0 && s_dirty[t];
     }
-
 #if KPEG_SYNC_STATS
-    if (t == 0) { atomicAdd(&a.status[8], st_rounds); atomicMax(&a.status[9], st_rounds); }
+    atomicAdd(&a.status[10], st_runs);
+    atomicAdd(&a.status[12], st_iters);
+    if (t == 0) {
+        atomicAdd(&a.status[8], st_rounds);
+        atomicMax(&a.status[9], st_rounds);
+        atomicAdd(&a.status[11], 1u);
+    }
 #endif
-    if (valid) {
-        a.X[i] = myX;
-        a.cnt[i] = mycnt;
+
+    int4 tot = make_int4(0, 0, 0, 0);
+    if (t < nown) {
+        a.X[i0 + t] = s_X[wu + t + 1];
+        tot = s_cnt[t];
+        a.cnt[i0 + t] = tot;
     }
     // per-workgroup totals for the scan
-    int4 tot = mycnt;
     for (int o = 32; o > 0; o >>= 1) {
         tot.x += __shfl_down(tot.x, o);
         tot.y += __shfl_down(tot.y, o);
@@ -746,18 +815,21 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     }
     if ((t & 63) == 0) s_red[t >> 6] = tot;
     __syncthreads();
-    const uint32_t last = min((uint32_t)SYNC_WG - 1, nsub - 1 - i0);
     if (t == 0) {
         int4 w = s_red[0];
         for (int q = 1; q < SYNC_WG / 64; ++q) w = add4(w, s_red[q]);
         a.wsum[g] = w;
-    }
-    if (t == last) {
-        const bool moved = p == 0 ? true : (myX != x_at_entry);
-        Xb_cur[g] = myX;
-        mv_cur[g] = moved;
-        // the last workgroup has no successor: its movement needs no further pass
-        if (moved && i + 1 < nsub) atomicAdd(&a.meta->moved[p], 1u);
+        const uint64_t last = s_X[nit];
+        const bool known = (s_geo[wu] >> 31) != 0;   // first own sub-sequence opens a restart segment
+        a.assumed[g] = known ? X_NONE : s_X[wu];
+        Xb_cur[g] = last;
+        if (p == 0) {
+            // nothing is verified before pass 1
+            if (!known) atomicAdd(&a.meta->moved[0], 1u);
+        } else if (last != Xb_prev[g] && i0 + nown < nsub) {
+            // the last workgroup has no successor: its movement needs no further pass
+            atomicAdd(&a.meta->moved[p], 1u);
+        }
     }
 }
 
@@ -832,7 +904,7 @@ struct WriteArgs {
     const int4* cnt;     // per-sub-sequence (blocks started, dc sums)
     const int4* wsum;    // exclusive prefix of the per-workgroup totals
     const int4* prefix;  // materialised exclusive prefix (restart segments only, else null)
-    int16_t* coef;
+    int16_t* coef;       // cleared by K1's pass 0
     float* ebound;       // [block] K4's per-block error bound
     uint32_t nsub_cap;
     uint32_t nmcu;
@@ -840,40 +912,36 @@ struct WriteArgs {
     uint32_t* status;
 };
 
-constexpr int WB_STRIDE = 72;  // int16 per lane block buffer: 64 + 8 pad (144 bytes, conflict-free b128)
-
-__global__ __launch_bounds__(256) void k_write(WriteArgs a)
+// One lane per sub-sequence, one symbol per iteration (a flat state machine: the lanes of a
+// wavefront sit at different points of different blocks).  A block belongs to the lane in whose
+// sub-sequence its DC symbol starts; that lane decodes it to its end, however far that is, and
+// stores each coefficient straight into the cleared buffer (fire-and-forget 2-byte stores: no
+// per-lane block buffer in LDS, so the workgroups fit many to a CU and hide each other's latency).
+//   own == false : finishing a block that began in an earlier sub-sequence: its symbols are only stepped over
+//   k == 0       : next symbol is a DC symbol (a block starts, if this sub-sequence still has bits)
+__global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
 {
     __shared__ LdsTables T;
-    __shared__ __attribute__((aligned(16))) int16_t s_blk[256 * WB_STRIDE];
-    __shared__ int4 s_pre[256];
-    __shared__ uint4 s_flush[4][64];   // per wavefront: (block, error bound, owner lane) of blocks to write
-    __shared__ uint32_t s_bits[STAGE_LDS];
+    __shared__ int4 s_pre[SYNC_WG];
+    constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
+    __shared__ uint32_t s_bits[STAGE_CAP];
     const uint32_t nsub = a.meta->nsub;
-    if (blockIdx.x * 256u >= nsub) return;
+    const uint32_t i0 = blockIdx.x * SYNC_WG;
+    if (i0 >= nsub) return;
     load_tables(&T, a.tabs);
-    int16_t* blk = s_blk + threadIdx.x * WB_STRIDE;
+    const uint32_t i = i0 + threadIdx.x;
+    const uint32_t nseg = a.meta->nseg;
+    const uint32_t w0 = sub_geom(a.seg_off, a.sub_base, nseg, i0).pstart >> 5;
     {
-        uint4 z = make_uint4(0, 0, 0, 0);
-        uint4* b4 = reinterpret_cast<uint4*>(blk);
-        for (int q = 0; q < 8; ++q) b4[q] = z;
-    }
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    BitSrc w;
-    {
-        const SubGeom g0 = sub_geom(a.seg_off, a.sub_base, a.meta->nseg, blockIdx.x * 256u);
-        w.g = a.u;
-        w.lds = s_bits;
-        w.w0 = g0.pstart >> 5;
         const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
-        w.nw = min((uint32_t)STAGE_TOTAL, total_words > w.w0 ? total_words - w.w0 : 0u);
-        stage_bits(s_bits, a.u, w.w0, w.nw);
+        stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
     if (!a.prefix) {
+        // single segment: exclusive scan of cnt inside the workgroup + the workgroup's offset
         int4 v = i < nsub ? a.cnt[i] : make_int4(0, 0, 0, 0);
         s_pre[threadIdx.x] = v;
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
+        for (int o = 1; o < SYNC_WG; o <<= 1) {
             int4 t = make_int4(0, 0, 0, 0);
             if ((int)threadIdx.x >= o) t = s_pre[threadIdx.x - o];
             __syncthreads();
@@ -885,11 +953,8 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         s_pre[threadIdx.x] = make_int4(w.x + incl.x - v.x, w.y + incl.y - v.y, w.z + incl.z - v.z, w.w + incl.w - v.w);
     }
     __syncthreads();
-    // lanes past the last sub-sequence stay: they help to write the others' blocks
-    const uint32_t nseg = a.meta->nseg;
-    const uint32_t ii = min(i, nsub - 1);
-    const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, ii);
-    const uint64_t* X = a.X;
+    if (i >= nsub) return;
+    const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, i);
 
     DecState s;
     if (g.li == 0) {
@@ -897,7 +962,7 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
         s.c = 0;
         s.k = 0;
     } else {
-        s = unpack_state(X[ii - 1]);
+        s = unpack_state(a.X[i - 1]);
     }
     // block index and DC predictors at entry, relative to the segment start
     int4 pre;
@@ -905,11 +970,10 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
     if (a.prefix) {
         pre = make_int4(0, 0, 0, 0);
         if (g.li != 0) {
-            int4 pi = a.prefix[ii], p0 = a.prefix[first];
+            int4 pi = a.prefix[i], p0 = a.prefix[first];
             pre = make_int4(pi.x - p0.x, pi.y - p0.y, pi.z - p0.z, pi.w - p0.w);
         }
     } else {
-        // single segment: exclusive scan of cnt inside the workgroup + the workgroup's offset
         pre = s_pre[threadIdx.x];
     }
     const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
@@ -918,136 +982,79 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs a)
     uint32_t b = (uint32_t)pre.x;                  // next block to start, within the segment
     const uint32_t seg_pend = a.seg_off[g.seg + 1] * 8;
 
-    const uint32_t lane = threadIdx.x & 63;
-    int16_t* wave_blk = s_blk + (threadIdx.x & ~63u) * WB_STRIDE;
-    uint4* fl_q = s_flush[threadIdx.x >> 6];
     BitReader br;
-    br.init(w, s.p);
-    // One symbol per iteration for every lane (a flat state machine: the lanes of a wavefront sit at
-    // different points of different blocks, so nested per-block / per-symbol loops would make every
-    // lane wait for the longest block of each round).
-    //   own == false : finishing a block that began in an earlier sub-sequence; it belongs to the
-    //                  lane that started it, so its symbols are only stepped over
-    //   k == 0       : next symbol is a DC symbol (a block starts, if this sub-sequence still has bits)
+    br.init(s_bits, w0, s.p);
     uint32_t err = 0;
-    uint32_t p = s.p, k = s.k;
+    uint32_t p = s.p, k = s.k, tb = state_table(s);
     bool own = k == 0;
-    uint32_t cb = b % 3;                 // component of block b (== s.c at a block start of a valid stream)
-    uint32_t c = own ? cb : s.c;         // component whose tables are in use
-    int pred0 = pre.y, pred1 = pre.z, pred2 = pre.w;
+    // DC predictors rotate with the blocks: pd0 belongs to the next block to start (component b % 3,
+    // == the component of the table in use on a valid stream); DCDiff[c] += zz[0] (MCU.cpp:107)
+    const uint32_t cb = b % 3;
+    int pd0 = cb == 0 ? pre.y : (cb == 1 ? pre.z : pre.w);
+    int pd1 = cb == 0 ? pre.z : (cb == 1 ? pre.w : pre.y);
+    int pd2 = cb == 0 ? pre.w : (cb == 1 ? pre.y : pre.z);
     bool keep_ac = false;
-    uint64_t touched = 0;
     float Asum = 0.0f;   // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
     int nnz = 0;
-    bool active = i < nsub;
+    bool corner = true;  // all non-zero AC terms in the 2x2 corner: natural 1, 8, 9 = zig-zag 1, 2, 4
+    int16_t* blk = a.coef;
     for (;;) {
-        const bool indc = k == 0;
-        active = active && (indc ? (p < g.pend && b < blk_limit) : (own || p < seg_pend));
-        if (!__any(active)) break;   // wave-uniform: every lane stays for the cooperative write-out
-        const uint32_t tdc = c ? 1u : 0u;
-        bool done = false;
-        if (active) {
+        if (k == 0 ? !(p < g.pend && b < blk_limit) : !(own || p < seg_pend)) break;
         const uint32_t win = br.peek();
-        uint32_t sym, len;
-        const bool ok = decode_symbol(T, win, (int)((indc ? 0u : 2u) + tdc), sym, len);
-        if (!ok && own) err |= 8;
-        const uint32_t cat = sym & 15, run = sym >> 4;
-        const uint32_t bits = __builtin_amdgcn_ubfe(win << len, 32 - cat, cat);
-        const uint32_t half = (1u << cat) >> 1;
-        int val = (int)bits - (bits < half ? (int)((1u << cat) - 1u) : 0);   // EXTEND; 0 when cat == 0
-        const uint32_t used = len + cat;   // EOB and "no such code" have cat 0
-        p += used;
-        br.consume(w, used);
-        uint32_t nat = 0;
-        bool place;
-        if (indc) {
-            if (run) err |= 16;  // DC symbol with a run nibble: outside the contract
-            // DCDiff[c] += zz[0]   (MCU.cpp:107)
-            pred0 += c == 0 ? val : 0;
-            pred1 += c == 1 ? val : 0;
-            pred2 += c == 2 ? val : 0;
-            val = c == 0 ? pred0 : (c == 1 ? pred1 : pred2);
-            keep_ac = sym != 0;  // quirk Q1: a DC "EOB" drops the block's AC terms (MCU.cpp:97-100)
+        const uint32_t e = lut_entry(T, tb, win);
+        const int val = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
+        const uint32_t kraw = k + ((e >> 16) & 127);
+        const bool adv = kraw >= 64;
+        const int tdc = tb >= 2 * LUT_BYTES ? 1 : 0;   // chroma tables
+        p += e & 31;
+        br.consume(e & 31);
+        if (e & E_ISDC) {
+            const int n = pd0 + val;
+            pd0 = pd1;
+            pd1 = pd2;
+            pd2 = n;
+            if (e & E_BAD) err |= 8;
+            if (e & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
+            keep_ac = !(e & E_ZERO);     // quirk Q1: a DC "EOB" drops the block's AC terms (MCU.cpp:97-100)
             own = true;
-            touched = 0;
+            blk = a.coef + (size_t)(seg_mcu0 * 3 + b) * 64;
+#ifndef KPEG_ABLATE_WSTORE
+            blk[0] = (int16_t)n;
+#endif
+            Asum = fabsf(0.25f * (0x1.fffffep-2f * ((float)n * T.q00[tdc])));
             nnz = 0;
-            Asum = fabsf(0.25f * (0x1.fffffep-2f * ((float)val * T.q00[tdc])));
-            k = 1;               // coefficients placed so far + 1
-            place = true;
-            done = false;
+            corner = true;
         } else {
-            const uint32_t kn = k + run + 1;
-            const bool eob = sym == 0;
-            const bool over = kn > 64;
-            if (over && !eob && own) err |= 32;  // run past the end of the block
-            place = !eob && !over && own && keep_ac;
-            nat = T.zz[(kn - 1) & 63];
-            done = eob || kn >= 64;
-            k = kn;
-            if (place) {
-                touched |= 1ull << nat;
-                Asum += fabsf((float)val * T.mscale[tdc][nat]);
-                nnz += val != 0;
+            const bool zero = (e & E_ZERO) != 0;          // EOB (or no such code)
+            const bool over = kraw > 64 && !zero;         // run past the end of the block
+            if (own) {
+                if (e & E_BAD) err |= 8;
+                if (over) err |= 32;
+                if (keep_ac && !zero && !over) {
+                    const uint32_t pos = kraw - 1;        // zig-zag position of this coefficient, 1..63
+#ifndef KPEG_ABLATE_WSTORE
+                    blk[T.zz[pos]] = (int16_t)val;
+#endif
+                    Asum += fabsf((float)val * T.mscale_zz[tdc][pos]);
+                    nnz += val != 0;
+                    corner = corner && (val == 0 || pos == 1 || pos == 2 || pos == 4);
+                }
+                if (adv) {
+                    // the block is complete
+                    if (p > seg_pend + 32) err |= 64;  // ran off the end of the data
+                    // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
+                    const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
+                    a.ebound[seg_mcu0 * 3 + b] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : (corner ? -E : E);
+                    b++;
+                }
             }
         }
-#if KPEG_ABLATE_W != 3
-        if (place) blk[nat] = (int16_t)val;
-#endif
-        }
-        // Blocks completed in this iteration leave together: the owners queue (block, bound) and the
-        // wavefront writes the queued 128-byte blocks eight lanes to a block, so every store
-        // instruction fills whole cache lines (a lane flushing its own block alone would send eight
-        // 16-byte partial-line writes to L2: measured 2x the kernel's whole decode time).
-        const bool fl = done && own;   // done is false on lanes that sat this iteration out
-        const uint64_t flmask = __ballot(fl);
-        if (fl) {
-            if (p > seg_pend + 32) err |= 64;  // ran off the end of the data
-            const uint32_t gb = seg_mcu0 * 3 + b;
-            // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
-            const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
-            // sign bit: all non-zero AC terms in the 2x2 corner (natural positions 1, 8, 9)
-            const bool corner = (touched & ~0x302ull) == 0;
-            const float eb = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : (corner ? -E : E);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(flmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)flmask, 0));
-            fl_q[rank] = make_uint4(gb, __float_as_uint(eb), lane, 0);
-            b++;
-            cb = cb == 2 ? 0u : cb + 1;
-        }
-        if (flmask) {   // wave-uniform
-            const uint32_t nfl = (uint32_t)__popcll(flmask);
-            for (uint32_t j = lane >> 3; j < nfl; j += 8) {
-                const uint4 q = fl_q[j];
-                uint4* src = reinterpret_cast<uint4*>(wave_blk + q.z * WB_STRIDE) + (lane & 7);
-#if KPEG_ABLATE_W != 1 && KPEG_ABLATE_W != 2
-#if KPEG_ABLATE_W == 4
-                reinterpret_cast<uint4*>(a.coef + (size_t)(q.x & 4095) * 64)[lane & 7] = *src;
-                if ((lane & 7) == 0) a.ebound[q.x & 4095] = __uint_as_float(q.y);
-#elif KPEG_ABLATE_W == 5
-                if ((lane & 7) == 0) a.ebound[q.x] = __uint_as_float(q.y);
-#elif KPEG_ABLATE_W == 7
-                reinterpret_cast<uint4*>(a.coef + (size_t)q.x * 64)[lane & 7] = make_uint4(q.x, q.y, q.z, 1);
-#elif KPEG_ABLATE_W == 8
-                if ((lane & 7) == 0) a.ebound[q.x] = __uint_as_float(q.y + src->x);
-#elif KPEG_ABLATE_W == 6
-                reinterpret_cast<uint4*>(a.coef + (size_t)q.x * 64)[lane & 7] = *src;
-#else
-                reinterpret_cast<uint4*>(a.coef + (size_t)q.x * 64)[lane & 7] = *src;
-                if ((lane & 7) == 0) a.ebound[q.x] = __uint_as_float(q.y);
-#endif
-#endif
-#if KPEG_ABLATE_W != 2
-                *src = make_uint4(0, 0, 0, 0);
-#endif
-            }
-        }
-        if (done) {
-            k = 0;
-            c = cb;
-            own = true;
-        }
+        k = adv ? ((e >> 14) & 1u) : kraw;
+        tb += adv ? LUT_BYTES : 0u;
+        tb = tb == 6 * LUT_BYTES ? 0u : tb;
     }
     // the last sub-sequence of a segment must have produced the segment's last block
-    if (i < nsub && g.li + 1 == a.sub_base[g.seg + 1] - first && b < blk_limit) err |= 128;
+    if (g.li + 1 == a.sub_base[g.seg + 1] - first && b < blk_limit) err |= 128;
     if (err) atomicOr(&a.status[1], err);
 }
 
@@ -1095,13 +1102,14 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     const uint32_t nparts = (n + US_BLOCK_BYTES - 1) / US_BLOCK_BYTES;
     const uint32_t nsub_cap = (uint32_t)(((uint64_t)n * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS) + nseg_expected + 1;
     const uint32_t seg_cap = nseg_expected + 2;
+    const uint32_t nwg_cap = (nsub_cap + SYNC_WG - 1) / SYNC_WG;
     int rc;
     if ((rc = ent_grow(&S->d_u, &S->u_cap, (size_t)n + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_part, &S->part_cap, (size_t)nparts * sizeof(uint2), L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_segoff, &S->seg_cap, (size_t)seg_cap * 2 * sizeof(uint32_t), L.stream, err))) return rc;
-    if ((rc = ent_grow(&S->d_state, &S->state_cap, (size_t)nsub_cap * 8 + ((size_t)nsub_cap / SYNC_WG + 2) * 18 + 64, L.stream, err))) return rc;
+    if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 3 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 32, L.stream, err))) return rc;
-    if ((rc = ent_grow(&S->d_wsum, &S->wsum_cap, ((size_t)nsub_cap / SYNC_WG + 2) * 16, L.stream, err))) return rc;
+    if ((rc = ent_grow(&S->d_wsum, &S->wsum_cap, ((size_t)nwg_cap + 2) * 16, L.stream, err))) return rc;
     if (!S->d_meta) ENT_HIP(hipMalloc((void**)&S->d_meta, sizeof(EntropyMeta)));
     if (!S->d_tabs) ENT_HIP(hipMalloc((void**)&S->d_tabs, sizeof(EntropyTables)));
     if (!S->tabs_valid || std::memcmp(&S->h_tabs_cached, &tabs, sizeof(tabs)) != 0) {
@@ -1114,10 +1122,9 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
 
     uint32_t* seg_off = (uint32_t*)S->d_segoff;
     uint32_t* sub_base = seg_off + seg_cap;
-    const uint32_t nwg_cap = (nsub_cap + SYNC_WG - 1) / SYNC_WG;
     uint64_t* X = (uint64_t*)S->d_state;
     uint64_t* Xb = X + nsub_cap;
-    uint8_t* mv = (uint8_t*)(Xb + 2 * (size_t)nwg_cap);
+    uint64_t* assumed = Xb + 2 * (size_t)nwg_cap;
     int4* cnt = (int4*)S->d_cnt;
     int4* prefix = cnt + nsub_cap;
     const int rst = L.restart_interval ? 1 : 0;
@@ -1138,9 +1145,11 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     sa.tabs = S->d_tabs;
     sa.X = X;
     sa.Xb = Xb;
-    sa.mv = mv;
+    sa.assumed = assumed;
     sa.cnt = cnt;
     sa.wsum = (int4*)S->d_wsum;
+    sa.coef16 = (uint4*)L.d_coef;
+    sa.coef_n16 = (uint64_t)L.nmcu * 24;   // 384 bytes per MCU
     sa.nwg_cap = nwg_cap;
     sa.status = L.d_status;
     const int npass = L.sync_passes > 0 ? L.sync_passes : SYNC_PASSES;
@@ -1172,7 +1181,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     wa.nmcu = L.nmcu;
     wa.interval = L.restart_interval;
     wa.status = L.d_status;
-    hipLaunchKernelGGL(k_write, dim3(nwg_cap), dim3(256), 0, L.stream, wa);
+    hipLaunchKernelGGL(k_write, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);
     mark(5);
     ENT_HIP(hipGetLastError());
