@@ -74,8 +74,9 @@ constexpr int POOL_SUBS = KPEG_POOL_SUBS;             // second-level tables sha
 //   [14] entry of a DC table             [15] symbol 0x00 (DC: quirk Q1, AC: EOB) or no such code
 //   [22:16] coefficient advance: AC run + 1, EOB / no such code 64, DC 65 (>= 64 ends the table's turn)
 //   [23] no such code                    [24] DC symbol with a run nibble (outside the contract)
+//   [25] DC symbol other than 0x00: the block keeps its AC terms (quirk Q1)
 //   [31] code longer than LUT_BITS: [15:0] = second-level table in the pool, E_SEARCH = none left
-constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_LONG = 1u << 31;
+constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_KEEP = 1u << 25, E_LONG = 1u << 31;
 constexpr uint32_t E_SEARCH = 0xFFFFu;
 
 __host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool isdc)
@@ -83,7 +84,7 @@ __host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool 
     const uint32_t cat = sym & 15, run = sym >> 4;
     const uint32_t kadv = isdc ? 65u : (sym == 0 ? 64u : run + 1);
     return (len + cat) | (len << 5) | (cat << 10) | (isdc ? E_ISDC : 0u) | (sym == 0 ? E_ZERO : 0u) | (kadv << 16) |
-           ((isdc && run) ? E_DCRUN : 0u);
+           ((isdc && run) ? E_DCRUN : 0u) | ((isdc && sym != 0) ? E_KEEP : 0u);
 }
 // no such code: keep moving by 16 bits (only a speculative decode or a corrupt stream gets here;
 // the reference would never leave its bit loop, Decoder.cpp:704-748)
@@ -99,7 +100,7 @@ struct EntropyTables {  // built on the host per frame, copied to the device whe
     int32_t valoff[4][18];           // symbol index of the first code of each length minus that code
     uint8_t symbols[4][256];
     uint8_t zz[64];                  // zig-zag -> natural
-    float mscale_zz[2][64];          // 0.25 * cc[u][v] * Q[u][v] by zig-zag position ([.][0] unused): K4's input scale
+    float mscale_zz[2][64];          // 0.25 * cc[u][v] * Q[u][v] by zig-zag position: K4's input scale
     float q00[2];                    // Q[0][0] of both tables
 };
 
@@ -114,6 +115,7 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
             const float cc = (u == 0 ? c0 : 1.0f) * (v == 0 ? c0 : 1.0f);
             t->mscale_zz[tq][k] = 0.25f * cc * (float)f->qt[tq][k];
         }
+        t->mscale_zz[tq][0] = 0.25f * (0x1.fffffep-2f * (float)f->qt[tq][0]);  // the reference's own cc[0][0] (Transform.cpp), as K4 uses it
         t->q00[tq] = (float)f->qt[tq][0];
     }
     int nsub = 0;
@@ -411,10 +413,11 @@ struct DecState {   // at a codeword boundary
     uint32_t p;     // bit position in the un-stuffed string
     uint32_t c;     // component 0..2 of the block being decoded
     uint32_t k;     // 0: next symbol is the DC symbol; 1..63: AC, k-1 coefficients placed so far
+    uint32_t q;     // k != 0: 1 if the block in progress keeps its AC terms (its DC symbol was not 0x00, quirk Q1); else 0
 };
 __device__ __forceinline__ uint64_t pack_state(const DecState& s)
 {
-    return (uint64_t)s.p | ((uint64_t)s.c << 32) | ((uint64_t)s.k << 34);
+    return (uint64_t)s.p | ((uint64_t)s.c << 32) | ((uint64_t)s.k << 34) | ((uint64_t)s.q << 41);
 }
 __device__ __forceinline__ DecState unpack_state(uint64_t v)
 {
@@ -422,6 +425,7 @@ __device__ __forceinline__ DecState unpack_state(uint64_t v)
     s.p = (uint32_t)v;
     s.c = (uint32_t)(v >> 32) & 3;
     s.k = (uint32_t)(v >> 34) & 127;
+    s.q = (uint32_t)(v >> 41) & 1;
     return s;
 }
 
@@ -547,7 +551,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
 {
     BitReader br;
     br.init(bits, w0, s.p);
-    uint32_t p = s.p, k = s.k, tb = state_table(s);
+    uint32_t p = s.p, k = s.k, q = s.q, tb = state_table(s);
     const uint32_t cfirst = s.k == 0 ? s.c : (s.c == 2 ? 0u : s.c + 1);  // component of the first block started here
     // DC sums rotate with the blocks: the current block's component adds into the slot that moves to the back
     int s0 = 0, s1 = 0, s2 = 0;
@@ -568,6 +572,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
             nb++;
         }
         k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
+        q = adv ? ((e >> 25) & 1u) : q;
         tb += adv ? LUT_BYTES : 0u;
         tb = tb == 6 * LUT_BYTES ? 0u : tb;
         p += e & 31;
@@ -587,6 +592,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
     x.p = p;
     x.c = tb / (2 * LUT_BYTES);
     x.k = k;
+    x.q = q;
     r.exit_state = pack_state(x);
 #if KPEG_SYNC_STATS
     r.iters = iters;
@@ -640,6 +646,9 @@ struct SyncArgs {
     int4* wsum;         // [nwg_cap] per-workgroup totals of cnt
     uint4* coef16;      // pass 0 clears the coefficient buffer, a slice per workgroup, behind its decode
     uint64_t coef_n16;
+    uint32_t* ebound;   // ... and presets K4's per-block bounds to +inf (a block K2 leaves out takes K4's exact path)
+    uint32_t nblocks;
+    unsigned long long* bslot;  // [nwg_cap] K2's exchange slots for blocks split over two workgroups: cleared here
     uint32_t nwg_cap;
     int pass;
     uint32_t* status;   // KPEG_SYNC_STATS builds only: words 8..13 collect loop counts
@@ -722,6 +731,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 s.p = geo.pstart;
                 s.c = 0;
                 s.k = 0;
+                s.q = 0;
                 const RunResult r = run_count(T, s_bits, w0, s, geo.pend);
 #if KPEG_SYNC_STATS
                 st_runs++;
@@ -755,6 +765,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         const uint64_t b0 = (uint64_t)g * per, b1 = min(a.coef_n16, b0 + per);
         const uint4 z = make_uint4(0, 0, 0, 0);
         for (uint64_t q = b0 + t; q < b1; q += SYNC_WG) a.coef16[q] = z;
+        const uint32_t eper = (a.nblocks + nwg - 1) / nwg;
+        const uint32_t e0 = min(a.nblocks, g * eper), e1 = min(a.nblocks, e0 + eper);
+        for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = 0x7F800000u;
+        if (t == 0) a.bslot[g] = 0ull;
     }
 #endif
     for (uint32_t round = 0;; ++round) {
@@ -909,20 +923,27 @@ struct WriteArgs {
     uint32_t nsub_cap;
     uint32_t nmcu;
     uint32_t interval;   // 0 = none
+    unsigned long long* bslot;  // [nwg_cap] exchange slots, slot g: the block split between workgroups g and g + 1
     uint32_t* status;
 };
 
 // One lane per sub-sequence, one symbol per iteration (a flat state machine: the lanes of a
-// wavefront sit at different points of different blocks).  A block belongs to the lane in whose
-// sub-sequence its DC symbol starts; that lane decodes it to its end, however far that is, and
-// stores each coefficient straight into the cleared buffer (fire-and-forget 2-byte stores: no
-// per-lane block buffer in LDS, so the workgroups fit many to a CU and hide each other's latency).
-//   own == false : finishing a block that began in an earlier sub-sequence: its symbols are only stepped over
-//   k == 0       : next symbol is a DC symbol (a block starts, if this sub-sequence still has bits)
+// wavefront sit at different points of different blocks).  A lane handles exactly the symbols of
+// its own sub-sequence -- no lane waits for another one's long block -- and stores each
+// coefficient straight into the cleared buffer (fire-and-forget 2-byte stores: no per-lane block
+// buffer in LDS, so the workgroups fit many to a CU and hide each other's latency).  The entry
+// state says where inside which block the lane starts (block index and DC predictors from the
+// scan, coefficient position k, quirk-Q1 flag q from the exit state of its predecessor).
+// K4's per-block error bound needs sums over the whole block: a block that starts and ends in one
+// lane is settled there; for a block split over lanes every lane leaves its share in LDS and the
+// lane that holds the block's end adds the shares up, walking back to the lane that started it.
+// A block split over two workgroups: both sides swap their sum into an exchange slot, and the side that
+// finds the other's sum there settles the bound.  Bounds are preset to +inf (K4's exact path), so a
+// block nobody settles (corrupt stream) is still decoded correctly.
 __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
 {
     __shared__ LdsTables T;
-    __shared__ int4 s_pre[SYNC_WG];
+    __shared__ int4 s_pre[SYNC_WG];   // first the scan of cnt, then every lane's share of the block open at its exit
     constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
     const uint32_t nsub = a.meta->nsub;
@@ -953,108 +974,187 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         s_pre[threadIdx.x] = make_int4(w.x + incl.x - v.x, w.y + incl.y - v.y, w.z + incl.z - v.z, w.w + incl.w - v.w);
     }
     __syncthreads();
-    if (i >= nsub) return;
-    const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, i);
 
-    DecState s;
-    if (g.li == 0) {
-        s.p = g.pstart;
-        s.c = 0;
-        s.k = 0;
-    } else {
-        s = unpack_state(a.X[i - 1]);
-    }
-    // block index and DC predictors at entry, relative to the segment start
-    int4 pre;
-    const uint32_t first = a.sub_base[g.seg];
-    if (a.prefix) {
-        pre = make_int4(0, 0, 0, 0);
-        if (g.li != 0) {
-            int4 pi = a.prefix[i], p0 = a.prefix[first];
-            pre = make_int4(pi.x - p0.x, pi.y - p0.y, pi.z - p0.z, pi.w - p0.w);
-        }
-    } else {
-        pre = s_pre[threadIdx.x];
-    }
-    const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
-    const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
-    const uint32_t blk_limit = seg_mcus * 3;       // blocks of this segment
-    uint32_t b = (uint32_t)pre.x;                  // next block to start, within the segment
-    const uint32_t seg_pend = a.seg_off[g.seg + 1] * 8;
-
-    BitReader br;
-    br.init(s_bits, w0, s.p);
     uint32_t err = 0;
-    uint32_t p = s.p, k = s.k, tb = state_table(s);
-    bool own = k == 0;
-    // DC predictors rotate with the blocks: pd0 belongs to the next block to start (component b % 3,
-    // == the component of the table in use on a valid stream); DCDiff[c] += zz[0] (MCU.cpp:107)
-    const uint32_t cb = b % 3;
-    int pd0 = cb == 0 ? pre.y : (cb == 1 ? pre.z : pre.w);
-    int pd1 = cb == 0 ? pre.z : (cb == 1 ? pre.w : pre.y);
-    int pd2 = cb == 0 ? pre.w : (cb == 1 ? pre.y : pre.z);
-    bool keep_ac = false;
-    float Asum = 0.0f;   // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
-    int nnz = 0;
-    bool corner = true;  // all non-zero AC terms in the 2x2 corner: natural 1, 8, 9 = zig-zag 1, 2, 4
-    int16_t* blk = a.coef;
-    for (;;) {
-        if (k == 0 ? !(p < g.pend && b < blk_limit) : !(own || p < seg_pend)) break;
-        const uint32_t win = br.peek();
-        const uint32_t e = lut_entry(T, tb, win);
-        const int val = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
-        const uint32_t kraw = k + ((e >> 16) & 127);
-        const bool adv = kraw >= 64;
-        const int tdc = tb >= 2 * LUT_BYTES ? 1 : 0;   // chroma tables
-        p += e & 31;
-        br.consume(e & 31);
-        if (e & E_ISDC) {
-            const int n = pd0 + val;
-            pd0 = pd1;
-            pd1 = pd2;
-            pd2 = n;
-            if (e & E_BAD) err |= 8;
-            if (e & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
-            keep_ac = !(e & E_ZERO);     // quirk Q1: a DC "EOB" drops the block's AC terms (MCU.cpp:97-100)
-            own = true;
-            blk = a.coef + (size_t)(seg_mcu0 * 3 + b) * 64;
-#ifndef KPEG_ABLATE_WSTORE
-            blk[0] = (int16_t)n;
-#endif
-            Asum = fabsf(0.25f * (0x1.fffffep-2f * ((float)n * T.q00[tdc])));
-            nnz = 0;
-            corner = true;
+    // the block open at this lane's entry, if it ends here: this lane's share of its bound
+    bool head = false;
+    float hA = 0.0f;
+    int hnnz = 0;
+    bool hcorner = true;
+    uint32_t hgb = 0;
+    int hchroma = 0;
+    // this lane's share of the block open at its exit: (A, nnz, flags)
+    int4 share = make_int4(0, 0, 0, 0);
+    uint32_t tail_gb = 0;
+    int tail_chroma = 0;
+    constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
+    int4 pre = make_int4(0, 0, 0, 0);
+    if (!a.prefix) pre = s_pre[threadIdx.x];
+    if (i < nsub) {
+        const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, i);
+        DecState s;
+        if (g.li == 0) {
+            s.p = g.pstart;
+            s.c = 0;
+            s.k = 0;
+            s.q = 0;
         } else {
-            const bool zero = (e & E_ZERO) != 0;          // EOB (or no such code)
-            const bool over = kraw > 64 && !zero;         // run past the end of the block
-            if (own) {
-                if (e & E_BAD) err |= 8;
-                if (over) err |= 32;
-                if (keep_ac && !zero && !over) {
-                    const uint32_t pos = kraw - 1;        // zig-zag position of this coefficient, 1..63
-#ifndef KPEG_ABLATE_WSTORE
-                    blk[T.zz[pos]] = (int16_t)val;
-#endif
-                    Asum += fabsf((float)val * T.mscale_zz[tdc][pos]);
-                    nnz += val != 0;
-                    corner = corner && (val == 0 || pos == 1 || pos == 2 || pos == 4);
-                }
-                if (adv) {
-                    // the block is complete
-                    if (p > seg_pend + 32) err |= 64;  // ran off the end of the data
-                    // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
-                    const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
-                    a.ebound[seg_mcu0 * 3 + b] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : (corner ? -E : E);
-                    b++;
-                }
+            s = unpack_state(a.X[i - 1]);
+        }
+        // block index and DC predictors at entry, relative to the segment start
+        const uint32_t first = a.sub_base[g.seg];
+        if (a.prefix) {
+            if (g.li != 0) {
+                int4 pi = a.prefix[i], p0 = a.prefix[first];
+                pre = make_int4(pi.x - p0.x, pi.y - p0.y, pi.z - p0.z, pi.w - p0.w);
             }
         }
-        k = adv ? ((e >> 14) & 1u) : kraw;
-        tb += adv ? LUT_BYTES : 0u;
-        tb = tb == 6 * LUT_BYTES ? 0u : tb;
+        const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
+        const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
+        const uint32_t blk_limit = seg_mcus * 3;       // blocks of this segment
+        uint32_t b = (uint32_t)pre.x;                  // blocks started so far, within the segment
+
+        BitReader br;
+        br.init(s_bits, w0, s.p);
+        uint32_t p = s.p, k = s.k, tb = state_table(s);
+        // DC predictors rotate with the blocks: pd0 belongs to the next block to start (component b % 3,
+        // == the component of the table in use on a valid stream); DCDiff[c] += zz[0] (MCU.cpp:107)
+        const uint32_t cb = b % 3;
+        int pd0 = cb == 0 ? pre.y : (cb == 1 ? pre.z : pre.w);
+        int pd1 = cb == 0 ? pre.z : (cb == 1 ? pre.w : pre.y);
+        int pd2 = cb == 0 ? pre.w : (cb == 1 ? pre.y : pre.z);
+        // state of the block in progress, as bits of one register (booleans would live in SGPR masks
+        // that the compiler re-merges every iteration)
+        constexpr uint32_t F_KEEP = 1;       // keeps its AC terms: quirk Q1, a DC "EOB" drops them (MCU.cpp:97-100)
+        constexpr uint32_t F_STARTED = 2;    // began in this lane
+        constexpr uint32_t F_NONCORNER = 4;  // has a non-zero AC term outside the 2x2 corner (natural 1, 8, 9 = zig-zag 1, 2, 4)
+        constexpr uint32_t F_OVER = 1u << 8; // error: a run went past the end of a block
+        constexpr uint32_t F_HEAD = 1u << 9, F_HEAD_NONCORNER = 1u << 10;   // the block open at entry ended here; its F_NONCORNER
+        uint32_t F = s.q ? F_KEEP : 0u;
+        uint32_t ebits = 0;                  // E_BAD / E_DCRUN of every entry met
+        float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
+        int nnz = 0;
+        const uint32_t gbase = seg_mcu0 * 3;
+        uint32_t gb = gbase + (b ? b - 1 : 0);          // block in progress
+        if (k != 0 && b == 0) err |= 64;                // inside a block before the segment's first one began
+        while (p < g.pend && !(k == 0 && b >= blk_limit)) {
+            const uint32_t win = br.peek();
+            const uint32_t e = lut_entry(T, tb, win);
+            p += e & 31;
+            br.consume(e & 31);
+            const int ext = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
+            const uint32_t kraw = k + ((e >> 16) & 127);
+            const bool adv = kraw >= 64;
+            const bool isdc = (e & E_ISDC) != 0;
+            const uint32_t tdc = tb >= 2 * LUT_BYTES ? 1u : 0u;   // chroma tables
+            ebits |= e;
+            // a DC symbol opens block gbase + b; its value is coefficient 0
+            const int n = pd0 + ext;
+            if (isdc) {
+                pd0 = pd1;
+                pd1 = pd2;
+                pd2 = n;
+                gb = gbase + b;
+                b++;
+                F = (F & (F_OVER | F_HEAD | F_HEAD_NONCORNER)) | F_STARTED | ((e >> 25) & 1u);   // E_KEEP -> F_KEEP
+            }
+            const int v = isdc ? n : ext;
+            // zig-zag position: DC 0; AC kraw - 1, which is >= 64 for an EOB, "no such code" and a run past the end
+            const uint32_t posraw = kraw - 1, pos = posraw & 63;
+            if (!isdc && !(e & E_ZERO) && kraw > 64) F |= F_OVER;
+            if (isdc || ((F & F_KEEP) && posraw < 64)) {
+                a.coef[((size_t)gb << 6) | T.zz[pos]] = (int16_t)v;
+                // == the terms of block_ebound()'s A in idct_colour.hip.h (DC: 0.25 cc00 Q00, any rounding order is inside U's slack)
+                Asum += fabsf((float)v * T.mscale_zz[tdc][pos]);
+                if (v != 0 && !isdc) {
+                    nnz++;
+                    if (!((0x16u >> min(pos, 31u)) & 1u)) F |= F_NONCORNER;
+                }
+            }
+            if (adv && !isdc) {
+                // the block is complete
+                if (F & F_STARTED) {
+                    // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
+                    const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
+                    a.ebound[gb] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : ((F & F_NONCORNER) ? E : -E);
+                } else {
+                    F |= F_HEAD | ((F & F_NONCORNER) ? F_HEAD_NONCORNER : 0u);
+                    hA = Asum;
+                    hnnz = nnz;
+                    hgb = gb;
+                    hchroma = (int)tdc;
+                }
+                F &= F_OVER | F_HEAD | F_HEAD_NONCORNER;
+                Asum = 0.0f;
+                nnz = 0;
+            }
+            k = adv ? ((e >> 14) & 1u) : kraw;
+            tb += adv ? LUT_BYTES : 0u;
+            tb = tb == 6 * LUT_BYTES ? 0u : tb;
+        }
+        if (ebits & E_BAD) err |= 8;
+        if (ebits & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
+        if (F & F_OVER) err |= 32;       // run past the end of a block
+        head = (F & F_HEAD) != 0;
+        hcorner = !(F & F_HEAD_NONCORNER);
+        tail_gb = gb;
+        tail_chroma = tb >= 2 * LUT_BYTES ? 1 : 0;
+        if (k != 0)
+            share = make_int4(__float_as_int(Asum), nnz, SH_OPEN | ((F & F_NONCORNER) ? 0 : SH_CORNER) | ((F & F_STARTED) ? SH_STARTED : 0), 0);
+        // the last sub-sequence of a segment must have produced the segment's last block, all of it
+        if (g.li + 1 == a.sub_base[g.seg + 1] - first) {
+            if (b < blk_limit) err |= 128;
+            if (k != 0) err |= 64;
+        }
     }
-    // the last sub-sequence of a segment must have produced the segment's last block
-    if (g.li + 1 == a.sub_base[g.seg + 1] - first && b < blk_limit) err |= 128;
+    __syncthreads();   // every lane has read its s_pre
+    s_pre[threadIdx.x] = share;
+    __syncthreads();
+    // (A, nnz, all-in-corner) of a split block as one 64-bit word for the exchange slots; never 0
+    auto pack = [](float A, int n, bool crn) -> unsigned long long {
+        return (unsigned long long)__float_as_uint(A) | ((unsigned long long)(uint32_t)n << 32) | ((unsigned long long)(crn ? 1u : 0u) << 40) |
+               (1ull << 63);
+    };
+    auto settle = [&](uint32_t blk, float A, int n, bool crn, int chroma) {
+        const float E = n ? (0x1.004p-24f * A) * ((float)n + 14.5f) : 0.0f;
+        if (A < (chroma ? 249.0f : 31000.0f)) a.ebound[blk] = crn ? -E : E;   // else the preset +inf stands
+    };
+    const uint32_t nown = min((uint32_t)SYNC_WG, nsub - i0);
+    const bool tail = threadIdx.x == nown - 1 && (share.z & SH_OPEN);   // the workgroup's last lane leaves a block open
+    for (int side = 0; side < 2; ++side) {
+        // side 0: the block open at entry that ended here; side 1: the block the workgroup's last lane leaves open
+        if (side == 0 ? !head : !tail) continue;
+        // add the shares of the lanes before this one, back to the lane where the block began
+        float A = side == 0 ? hA : __int_as_float(share.x);
+        int n = side == 0 ? hnnz : share.y;
+        bool crn = side == 0 ? hcorner : (share.z & SH_CORNER) != 0;
+        bool found = side == 1 && (share.z & SH_STARTED), broken = false;
+        for (int j = (int)threadIdx.x - 1; j >= 0 && !found && !broken; --j) {
+            const int4 sh = s_pre[j];
+            if (!(sh.z & SH_OPEN)) {
+                broken = true;   // inconsistent (corrupt stream): the preset +inf stands
+            } else {
+                A += __int_as_float(sh.x);
+                n += sh.y;
+                crn = crn && (sh.z & SH_CORNER);
+                found = (sh.z & SH_STARTED) != 0;
+            }
+        }
+        if (side == 0 && found) settle(hgb, A, n, crn, hchroma);
+        // the part of the block on this side of a workgroup boundary: swap it for the other side's
+        const bool to_prev = side == 0 && !found && !broken && blockIdx.x > 0;   // began before this workgroup
+        const bool to_next = side == 1 && found;                                  // goes on after this workgroup
+        if (to_prev || to_next) {
+            const unsigned long long other = atomicExch(&a.bslot[to_prev ? blockIdx.x - 1 : blockIdx.x], pack(A, n, crn));
+            if (other) {
+                // the sum runs in stream order on both sides: earlier part + later part
+                const float Ao = __uint_as_float((uint32_t)other);
+                const int no = (int)((other >> 32) & 0xFF);
+                const bool co = ((other >> 40) & 1) != 0;
+                settle(to_prev ? hgb : tail_gb, to_prev ? Ao + A : A + Ao, n + no, crn && co, to_prev ? hchroma : tail_chroma);
+            }
+        }
+    }
     if (err) atomicOr(&a.status[1], err);
 }
 
@@ -1107,7 +1207,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     if ((rc = ent_grow(&S->d_u, &S->u_cap, (size_t)n + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_part, &S->part_cap, (size_t)nparts * sizeof(uint2), L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_segoff, &S->seg_cap, (size_t)seg_cap * 2 * sizeof(uint32_t), L.stream, err))) return rc;
-    if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 3 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
+    if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 4 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 32, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_wsum, &S->wsum_cap, ((size_t)nwg_cap + 2) * 16, L.stream, err))) return rc;
     if (!S->d_meta) ENT_HIP(hipMalloc((void**)&S->d_meta, sizeof(EntropyMeta)));
@@ -1125,6 +1225,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     uint64_t* X = (uint64_t*)S->d_state;
     uint64_t* Xb = X + nsub_cap;
     uint64_t* assumed = Xb + 2 * (size_t)nwg_cap;
+    unsigned long long* bslot = (unsigned long long*)(assumed + nwg_cap);
     int4* cnt = (int4*)S->d_cnt;
     int4* prefix = cnt + nsub_cap;
     const int rst = L.restart_interval ? 1 : 0;
@@ -1150,6 +1251,9 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     sa.wsum = (int4*)S->d_wsum;
     sa.coef16 = (uint4*)L.d_coef;
     sa.coef_n16 = (uint64_t)L.nmcu * 24;   // 384 bytes per MCU
+    sa.ebound = (uint32_t*)L.d_ebound;
+    sa.nblocks = L.nmcu * 3;
+    sa.bslot = bslot;
     sa.nwg_cap = nwg_cap;
     sa.status = L.d_status;
     const int npass = L.sync_passes > 0 ? L.sync_passes : SYNC_PASSES;
@@ -1180,6 +1284,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     wa.nsub_cap = nsub_cap;
     wa.nmcu = L.nmcu;
     wa.interval = L.restart_interval;
+    wa.bslot = bslot;
     wa.status = L.d_status;
     hipLaunchKernelGGL(k_write, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);
