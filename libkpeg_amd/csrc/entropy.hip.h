@@ -44,6 +44,9 @@
 
 namespace kpeg_dev {
 
+#ifndef KPEG_ABLATE_W
+#define KPEG_ABLATE_W 0   // timing experiments only (tools/variants.sh)
+#endif
 #ifndef KPEG_SYNC_STATS
 #define KPEG_SYNC_STATS 0   // 1: loop counts into status words 8..13 (tools/sync_dbg.py)
 #endif
@@ -55,11 +58,16 @@ namespace kpeg_dev {
 #endif
 constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable: 64, 128, 256, 512)
 constexpr int SUBSEQ_WORDS = SUBSEQ_BITS / 32;
-constexpr int SYNC_WG = KPEG_SYNC_WG;          // sub-sequences (and threads) per workgroup
+constexpr int SYNC_WG = KPEG_SYNC_WG;          // threads per workgroup of K1 and K2
 constexpr int SYNC_PASSES = 4;   // sync kernels enqueued per call: pass 0, the verifying pass 1, boundary passes (idle ones exit at once)
-constexpr int WARM_BITS = 1024;  // a workgroup decodes this much of its predecessor's tail to find its own entry state
+#ifndef KPEG_WARM_BITS
+#define KPEG_WARM_BITS 1024
+#endif
+constexpr int WARM_BITS = KPEG_WARM_BITS;  // a workgroup decodes this much of its predecessor's tail to find its own entry state
 constexpr int WARM = (WARM_BITS + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
-constexpr int ITEMS = SYNC_WG + WARM;
+constexpr int OWN = SYNC_WG - WARM;   // sub-sequences per workgroup: with the warm-up ones a thread each
+constexpr int ITEMS = SYNC_WG;
+static_assert(OWN >= WARM && OWN >= 64, "workgroup too small for the warm-up distance");
 static_assert(SUBSEQ_BITS >= 64 && SUBSEQ_BITS % 32 == 0, "a symbol (<= 31 bits) must not jump over a whole sub-sequence");
 
 constexpr int LUT_BITS = 9;
@@ -206,6 +214,7 @@ struct EntropyLaunch {
     uint32_t* d_status;
     int num_cus;
     int sync_passes;   // 0 = default
+    int warm;          // warm-up sub-sequences per workgroup, < 0 = default (test hook: 0 makes every workgroup guess wrong)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -504,7 +513,7 @@ struct BitReader {
 };
 
 // canonical search, for tables with more long-code prefixes than the pool holds (never for real tables)
-__device__ inline uint32_t search_entry(const LdsTables& T, uint32_t tb, uint32_t win)
+__device__ __attribute__((noinline)) uint32_t search_entry(const LdsTables& T, uint32_t tb, uint32_t win)
 {
     const uint32_t slot = tb / LUT_BYTES, ti = slot_table(slot);
     const bool isdc = !(slot & 1);
@@ -515,11 +524,16 @@ __device__ inline uint32_t search_entry(const LdsTables& T, uint32_t tb, uint32_
     return bad_entry(isdc);
 }
 
-// The entry of the symbol at the head of `win` (the next 32 bits), table at byte offset tb.
-__device__ __forceinline__ uint32_t lut_entry(const LdsTables& T, uint32_t tb, uint32_t win)
+// The entry of the symbol at the head of `win` (the next 32 bits), table at byte offset tb, in two
+// steps so that a decode loop can issue the first-level read of the next symbol before it finishes
+// the bookkeeping of the current one (the LDS latency is the longest link of the symbol-to-symbol chain).
+__device__ __forceinline__ uint32_t lut_first(const LdsTables& T, uint32_t tb, uint32_t win)
 {
     const char* base = reinterpret_cast<const char*>(&T.lut[0][0]);
-    uint32_t e = *reinterpret_cast<const uint32_t*>(base + tb + ((win >> (32 - LUT_BITS)) << 2));
+    return *reinterpret_cast<const uint32_t*>(base + tb + ((win >> (32 - LUT_BITS)) << 2));
+}
+__device__ __forceinline__ uint32_t lut_finish(const LdsTables& T, uint32_t tb, uint32_t win, uint32_t e)
+{
     if (e & E_LONG) {  // 10..16-bit code: one more table read
         const uint32_t sub = e & 0xFFFFu;
         e = sub != E_SEARCH ? T.pool[sub][(win >> (32 - 16)) & ((1u << LUT2_BITS) - 1)] : search_entry(T, tb, win);
@@ -559,11 +573,19 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
 #if KPEG_SYNC_STATS
     uint32_t iters = 0;
 #endif
+    uint32_t e1 = lut_first(T, tb, br.peek());
     while (p < pend) {
         const uint32_t win = br.peek();
-        const uint32_t e = lut_entry(T, tb, win);
+        const uint32_t e = lut_finish(T, tb, win, e1);
         const uint32_t kraw = k + ((e >> 16) & 127);
         const bool adv = kraw >= 64;   // this table's turn ends: DC symbol, EOB, 63rd coefficient (Decoder.cpp:759)
+        k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
+        q = adv ? ((e >> 25) & 1u) : q;
+        tb += adv ? LUT_BYTES : 0u;
+        tb = tb == 6 * LUT_BYTES ? 0u : tb;
+        p += e & 31;
+        br.consume(e & 31);
+        e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way (one read too many at the end: harmless)
         if (e & E_ISDC) {
             const int n = s0 + extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
             s0 = s1;
@@ -571,12 +593,6 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
             s2 = n;
             nb++;
         }
-        k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
-        q = adv ? ((e >> 25) & 1u) : q;
-        tb += adv ? LUT_BYTES : 0u;
-        tb = tb == 6 * LUT_BYTES ? 0u : tb;
-        p += e & 31;
-        br.consume(e & 31);
 #if KPEG_SYNC_STATS
         iters++;
 #endif
@@ -649,6 +665,9 @@ struct SyncArgs {
     uint32_t* ebound;   // ... and presets K4's per-block bounds to +inf (a block K2 leaves out takes K4's exact path)
     uint32_t nblocks;
     unsigned long long* bslot;  // [nwg_cap] K2's exchange slots for blocks split over two workgroups: cleared here
+    uint32_t* done;     // [nwg_cap] chained pass: workgroup g has published its final exit state
+    int chained;        // this pass waits for the predecessor workgroup instead of trusting the previous pass
+    uint32_t warm;      // warm-up sub-sequences (<= WARM)
     uint32_t nwg_cap;
     int pass;
     uint32_t* status;   // KPEG_SYNC_STATS builds only: words 8..13 collect loop counts
@@ -690,23 +709,47 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     const int p = a.pass;
     const uint32_t g = blockIdx.x, t = threadIdx.x;
     const uint32_t nsub = a.meta->nsub;
-    const uint32_t i0 = g * SYNC_WG;
+    const uint32_t i0 = g * OWN;
     if (i0 >= nsub) return;
     if (p >= 2 && a.meta->moved[p - 1] == 0) return;  // converged
     const uint64_t* Xb_prev = a.Xb + (size_t)((p & 1) ^ 1) * a.nwg_cap;
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
+    // Chained pass (the last one enqueued, only if the pass before it still moved something): every
+    // workgroup waits until its predecessor has published its final exit state, so one launch ends the
+    // ripple however far it has to run (workgroups are dispatched in index order: the predecessor is
+    // running or done).  Streams that re-synchronise slowly (dense noise) end here; it costs a chain
+    // of workgroup decodes, but no stream is given up.
+    uint64_t entry = 0;
     if (p >= 1) {
+        if (a.chained && g > 0) {
+            if (t == 0) {
+                while (__hip_atomic_load(&a.done[g - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+            entry = __hip_atomic_load(&Xb_cur[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (g > 0) {
+            entry = Xb_prev[g - 1];
+        }
         const uint64_t as = a.assumed[g];
-        if (g == 0 || as == X_NONE || as == Xb_prev[g - 1]) {
+        if (g == 0 || as == X_NONE || as == entry) {
             // the state this workgroup decoded from stands, and so do its results
-            if (t == 0) Xb_cur[g] = Xb_prev[g];
+            if (t == 0) {
+                Xb_cur[g] = Xb_prev[g];
+                if (a.chained) {
+                    __threadfence();
+                    __hip_atomic_store(&a.done[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             return;
         }
     }
+#if KPEG_SYNC_STATS
+    const uint64_t tm0 = __builtin_amdgcn_s_memtime();
+#endif
     load_tables(&T, a.tabs);
     const uint32_t nseg = a.meta->nseg;
-    const uint32_t nown = min((uint32_t)SYNC_WG, nsub - i0);
-    const uint32_t wu = p == 0 ? min((uint32_t)WARM, i0) : 0u;
+    const uint32_t nown = min((uint32_t)OWN, nsub - i0);
+    const uint32_t wu = p == 0 ? min(a.warm, i0) : 0u;
     const uint32_t ibase = i0 - wu, nit = wu + nown;
     // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
     const uint32_t w0 = sub_geom(a.seg_off, a.sub_base, nseg, ibase).pstart >> 5;
@@ -715,10 +758,18 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
     if (t < 3) s_n[t] = 0;
+    if (t == 0 && p == 0) {
+        // item 0 starts from its guess (matters as this workgroup's assumption only without warm-up)
+        DecState s0;
+        s0.p = sub_geom(a.seg_off, a.sub_base, nseg, ibase).pstart;
+        s0.c = s0.k = s0.q = 0;
+        s_X[0] = pack_state(s0);
+    }
     __syncthreads();
 
 #if KPEG_SYNC_STATS
     uint32_t st_runs = 0, st_iters = 0, st_rounds = 0;
+    const uint64_t tm1 = __builtin_amdgcn_s_memtime();
 #endif
     if (p == 0) {
         for (uint32_t jb = 0; jb < nit; jb += SYNC_WG) {
@@ -751,16 +802,20 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s_cnt[j] = a.cnt[i0 + j];
         }
         if (t == 0) {
-            s_X[0] = Xb_prev[g - 1];
+            s_X[0] = entry;
             s_list[0][0] = 0;
             s_n[0] = 1;
         }
     }
 
+#if KPEG_SYNC_STATS
+    __syncthreads();
+    const uint64_t tm2 = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef KPEG_ABLATE_NOZERO
     // pass 0 clears the coefficient buffer behind the rounds below, which only touch LDS
     if (p == 0) {
-        const uint32_t nwg = (nsub + SYNC_WG - 1) / SYNC_WG;   // the workgroups that get here
+        const uint32_t nwg = (nsub + OWN - 1) / OWN;   // the workgroups that get here
         const uint64_t per = (a.coef_n16 + nwg - 1) / nwg;
         const uint64_t b0 = (uint64_t)g * per, b1 = min(a.coef_n16, b0 + per);
         const uint4 z = make_uint4(0, 0, 0, 0);
@@ -768,7 +823,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         const uint32_t eper = (a.nblocks + nwg - 1) / nwg;
         const uint32_t e0 = min(a.nblocks, g * eper), e1 = min(a.nblocks, e0 + eper);
         for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = 0x7F800000u;
-        if (t == 0) a.bslot[g] = 0ull;
+        if (t == 0) {
+            a.bslot[g] = 0ull;
+            a.done[g] = 0u;
+        }
     }
 #endif
     for (uint32_t round = 0;; ++round) {
@@ -805,6 +863,12 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         }
     }
 #if KPEG_SYNC_STATS
+    const uint64_t tm3 = __builtin_amdgcn_s_memtime();
+    if (t == 0 && p == 0) {
+        atomicAdd(&a.status[13], (uint32_t)((tm1 - tm0) >> 4));
+        atomicAdd(&a.status[14], (uint32_t)((tm2 - tm1) >> 4));
+        atomicAdd(&a.status[15], (uint32_t)((tm3 - tm2) >> 4));
+    }
     atomicAdd(&a.status[10], st_runs);
     atomicAdd(&a.status[12], st_iters);
     if (t == 0) {
@@ -837,10 +901,14 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         const bool known = (s_geo[wu] >> 31) != 0;   // first own sub-sequence opens a restart segment
         a.assumed[g] = known ? X_NONE : s_X[wu];
         Xb_cur[g] = last;
+        if (a.chained) {
+            __threadfence();
+            __hip_atomic_store(&a.done[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (p == 0) {
             // nothing is verified before pass 1
             if (!known) atomicAdd(&a.meta->moved[0], 1u);
-        } else if (last != Xb_prev[g] && i0 + nown < nsub) {
+        } else if (!a.chained && last != Xb_prev[g] && i0 + nown < nsub) {
             // the last workgroup has no successor: its movement needs no further pass
             atomicAdd(&a.meta->moved[p], 1u);
         }
@@ -854,7 +922,7 @@ __global__ __launch_bounds__(1024) void k_scan_wsum(int4* wsum, EntropyMeta* met
     __shared__ int4 s[1024];
     __shared__ int4 carry;
     const uint32_t nsub = meta->nsub;
-    const uint32_t nw = (nsub + SYNC_WG - 1) / SYNC_WG;
+    const uint32_t nw = (nsub + OWN - 1) / OWN;
     if (threadIdx.x == 0) carry = make_int4(0, 0, 0, 0);
     __syncthreads();
     for (uint32_t base = 0; base < nw; base += 1024) {
@@ -890,9 +958,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_scan_apply(const int4* cnt, const i
 {
     __shared__ int4 s[SYNC_WG];
     const uint32_t nsub = meta->nsub;
-    uint32_t i = blockIdx.x * SYNC_WG + threadIdx.x;
-    if (blockIdx.x * SYNC_WG >= nsub) return;
-    int4 v = i < nsub ? cnt[i] : make_int4(0, 0, 0, 0);
+    uint32_t i = blockIdx.x * OWN + threadIdx.x;
+    if (blockIdx.x * OWN >= nsub) return;
+    const bool valid = threadIdx.x < OWN && i < nsub;
+    int4 v = valid ? cnt[i] : make_int4(0, 0, 0, 0);
     s[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < SYNC_WG; o <<= 1) {
@@ -903,7 +972,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_scan_apply(const int4* cnt, const i
         __syncthreads();
     }
     int4 incl = s[threadIdx.x], w = wsum[blockIdx.x];
-    if (i < nsub) prefix[i] = make_int4(w.x + incl.x - v.x, w.y + incl.y - v.y, w.z + incl.z - v.z, w.w + incl.w - v.w);
+    if (valid) prefix[i] = make_int4(w.x + incl.x - v.x, w.y + incl.y - v.y, w.z + incl.z - v.z, w.w + incl.w - v.w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -947,10 +1016,11 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
     const uint32_t nsub = a.meta->nsub;
-    const uint32_t i0 = blockIdx.x * SYNC_WG;
+    const uint32_t i0 = blockIdx.x * OWN;
     if (i0 >= nsub) return;
     load_tables(&T, a.tabs);
     const uint32_t i = i0 + threadIdx.x;
+    const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
     const uint32_t nseg = a.meta->nseg;
     const uint32_t w0 = sub_geom(a.seg_off, a.sub_base, nseg, i0).pstart >> 5;
     {
@@ -959,7 +1029,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     }
     if (!a.prefix) {
         // single segment: exclusive scan of cnt inside the workgroup + the workgroup's offset
-        int4 v = i < nsub ? a.cnt[i] : make_int4(0, 0, 0, 0);
+        int4 v = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
         s_pre[threadIdx.x] = v;
         __syncthreads();
         for (int o = 1; o < SYNC_WG; o <<= 1) {
@@ -990,7 +1060,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
     int4 pre = make_int4(0, 0, 0, 0);
     if (!a.prefix) pre = s_pre[threadIdx.x];
-    if (i < nsub) {
+    if (valid) {
         const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, i);
         DecState s;
         if (g.li == 0) {
@@ -1037,16 +1107,24 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         const uint32_t gbase = seg_mcu0 * 3;
         uint32_t gb = gbase + (b ? b - 1 : 0);          // block in progress
         if (k != 0 && b == 0) err |= 64;                // inside a block before the segment's first one began
+#if KPEG_ABLATE_W == 2
+        if (a.nmcu == 0)
+#endif
+        uint32_t e1 = lut_first(T, tb, br.peek());
         while (p < g.pend && !(k == 0 && b >= blk_limit)) {
             const uint32_t win = br.peek();
-            const uint32_t e = lut_entry(T, tb, win);
+            const uint32_t e = lut_finish(T, tb, win, e1);
             p += e & 31;
             br.consume(e & 31);
-            const int ext = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
             const uint32_t kraw = k + ((e >> 16) & 127);
             const bool adv = kraw >= 64;
             const bool isdc = (e & E_ISDC) != 0;
             const uint32_t tdc = tb >= 2 * LUT_BYTES ? 1u : 0u;   // chroma tables
+            k = adv ? ((e >> 14) & 1u) : kraw;
+            tb += adv ? LUT_BYTES : 0u;
+            tb = tb == 6 * LUT_BYTES ? 0u : tb;
+            e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way
+            const int ext = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
             ebits |= e;
             // a DC symbol opens block gbase + b; its value is coefficient 0
             const int n = pd0 + ext;
@@ -1063,7 +1141,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             const uint32_t posraw = kraw - 1, pos = posraw & 63;
             if (!isdc && !(e & E_ZERO) && kraw > 64) F |= F_OVER;
             if (isdc || ((F & F_KEEP) && posraw < 64)) {
+#if KPEG_ABLATE_W != 1 && KPEG_ABLATE_W != 3
                 a.coef[((size_t)gb << 6) | T.zz[pos]] = (int16_t)v;
+#endif
                 // == the terms of block_ebound()'s A in idct_colour.hip.h (DC: 0.25 cc00 Q00, any rounding order is inside U's slack)
                 Asum += fabsf((float)v * T.mscale_zz[tdc][pos]);
                 if (v != 0 && !isdc) {
@@ -1076,7 +1156,11 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                 if (F & F_STARTED) {
                     // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
                     const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
+#if KPEG_ABLATE_W != 3
                     a.ebound[gb] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : ((F & F_NONCORNER) ? E : -E);
+#else
+                    if (E == 123.0f) a.ebound[gb] = E;
+#endif
                 } else {
                     F |= F_HEAD | ((F & F_NONCORNER) ? F_HEAD_NONCORNER : 0u);
                     hA = Asum;
@@ -1088,9 +1172,6 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                 Asum = 0.0f;
                 nnz = 0;
             }
-            k = adv ? ((e >> 14) & 1u) : kraw;
-            tb += adv ? LUT_BYTES : 0u;
-            tb = tb == 6 * LUT_BYTES ? 0u : tb;
         }
         if (ebits & E_BAD) err |= 8;
         if (ebits & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
@@ -1119,7 +1200,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         const float E = n ? (0x1.004p-24f * A) * ((float)n + 14.5f) : 0.0f;
         if (A < (chroma ? 249.0f : 31000.0f)) a.ebound[blk] = crn ? -E : E;   // else the preset +inf stands
     };
-    const uint32_t nown = min((uint32_t)SYNC_WG, nsub - i0);
+    const uint32_t nown = min((uint32_t)OWN, nsub - i0);
     const bool tail = threadIdx.x == nown - 1 && (share.z & SH_OPEN);   // the workgroup's last lane leaves a block open
     for (int side = 0; side < 2; ++side) {
         // side 0: the block open at entry that ended here; side 1: the block the workgroup's last lane leaves open
@@ -1202,12 +1283,12 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     const uint32_t nparts = (n + US_BLOCK_BYTES - 1) / US_BLOCK_BYTES;
     const uint32_t nsub_cap = (uint32_t)(((uint64_t)n * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS) + nseg_expected + 1;
     const uint32_t seg_cap = nseg_expected + 2;
-    const uint32_t nwg_cap = (nsub_cap + SYNC_WG - 1) / SYNC_WG;
+    const uint32_t nwg_cap = (nsub_cap + OWN - 1) / OWN;
     int rc;
     if ((rc = ent_grow(&S->d_u, &S->u_cap, (size_t)n + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_part, &S->part_cap, (size_t)nparts * sizeof(uint2), L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_segoff, &S->seg_cap, (size_t)seg_cap * 2 * sizeof(uint32_t), L.stream, err))) return rc;
-    if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 4 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
+    if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 5 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 32, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_wsum, &S->wsum_cap, ((size_t)nwg_cap + 2) * 16, L.stream, err))) return rc;
     if (!S->d_meta) ENT_HIP(hipMalloc((void**)&S->d_meta, sizeof(EntropyMeta)));
@@ -1226,6 +1307,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     uint64_t* Xb = X + nsub_cap;
     uint64_t* assumed = Xb + 2 * (size_t)nwg_cap;
     unsigned long long* bslot = (unsigned long long*)(assumed + nwg_cap);
+    uint32_t* done = (uint32_t*)(bslot + nwg_cap);
     int4* cnt = (int4*)S->d_cnt;
     int4* prefix = cnt + nsub_cap;
     const int rst = L.restart_interval ? 1 : 0;
@@ -1254,11 +1336,14 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     sa.ebound = (uint32_t*)L.d_ebound;
     sa.nblocks = L.nmcu * 3;
     sa.bslot = bslot;
+    sa.done = done;
+    sa.warm = L.warm < 0 ? (uint32_t)WARM : min((uint32_t)L.warm, (uint32_t)WARM);
     sa.nwg_cap = nwg_cap;
     sa.status = L.d_status;
     const int npass = L.sync_passes > 0 ? L.sync_passes : SYNC_PASSES;
     for (int t = 0; t < npass; ++t) {
         sa.pass = t;
+        sa.chained = (t >= 2 && t == npass - 1) ? 1 : 0;
         hipLaunchKernelGGL(k_sync_pass, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
     }
     mark(2);

@@ -29,6 +29,7 @@ struct kpeg_hip_ctx {
     std::string last_error;
     int idct_mode = 0;
     int sync_passes = 0;  // 0 = default number of enqueued sync passes
+    int warm = -1;        // test hook: K1's warm-up sub-sequences per workgroup (< 0 = default)
     bool profiling = false;
     int num_cus = 256;
 
@@ -365,6 +366,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.d_status = ctx->d_status;
     L.num_cus = ctx->num_cus;
     L.sync_passes = ctx->sync_passes;
+    L.warm = ctx->warm;
     hipEvent_t* evs = ctx->profiling ? ctx->ev : nullptr;
     rc = entropy_decode_launch(&ctx->ent, tabs, L, evs, ctx->ev_rec, &ctx->last_error);
     return rc;
@@ -451,6 +453,16 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
         rc = kpeg_hip_decode_scan(ctx, f, scans[i], scan_lens[i], rgbs[i]);
         if (rc) return rc;
     }
+    return KPEG_HIP_OK;
+}
+
+// test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default)
+extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
+{
+    if (!ctx) return KPEG_HIP_E_ARG;
+    if (key == 1) ctx->sync_passes = value;
+    else if (key == 2) ctx->warm = value;
+    else return KPEG_HIP_E_ARG;
     return KPEG_HIP_OK;
 }
 

@@ -1,4 +1,6 @@
 """On-device entropy decode (K0..K2) and the whole seam (scan bytes -> RGB) vs the oracle."""
+import sys
+
 import numpy as np
 import pytest
 
@@ -44,6 +46,68 @@ def test_decode_scan_matches_oracle(ctx, w, h, q, sigma, smode):
     assert st == T.DECODE_DONE
     p = T.oracle_parse(data)
     ctx.set_idct_mode(0)
+    got = ctx.decode_scan(T.make_frame(p), p.scan)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, "first mismatches (y,x,c): %s of %d" % (bad[:8].tolist(), len(bad))
+
+
+def test_flat_image(ctx):
+    """A constant image is a periodic bit string (14 bits per MCU: DC diff 0 + EOB, three times)."""
+    rgb = np.empty((1024, 2048, 3), np.uint8)
+    rgb[:] = (200, 30, 77)
+    data = T.encode_rgb(rgb, quality=75)
+    st, want = T.oracle_decode(data)
+    assert st == T.DECODE_DONE
+    p = T.oracle_parse(data)
+    got = ctx.decode_scan(T.make_frame(p), p.scan)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, "first mismatches (y,x,c): %s of %d" % (bad[:8].tolist(), len(bad))
+
+
+_STRESS = r"""
+import sys
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import numpy as np, kpeg_testlib as T, libkpeg_amd
+ctx = libkpeg_amd.Context(0)
+worst = 0
+for (w, h, q, sigma, mode, warm) in [(1024, 512, 95, 0.0, 1, -1), (1024, 512, 95, 0.0, 1, 0), (1920, 1080, 75, 6.0, 0, 0), (512, 512, 30, 3.0, 0, -1)]:
+    data = T.synth_jpeg(w, h, seed=21, quality=q, sigma=sigma, mode=mode)
+    st, want = T.oracle_decode(data)
+    p = T.oracle_parse(data)
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 2, warm) == 0
+    got = ctx.decode_scan(T.make_frame(p), p.scan)
+    passes = int(ctx.timings()["sync_rounds"])
+    worst = max(worst, passes)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (w, h, q, mode, warm, passes, bad[:8].tolist(), len(bad))
+print("PASSES", worst)
+"""
+
+
+def test_boundary_passes_and_chained_pass_on_tiny_workgroups():
+    """libkpeg_hip_stress.so = the same sources with 127 x 64-bit sub-sequences per workgroup and a 64-bit
+    warm-up (libkpeg_amd/build.py): dense noise re-synchronises over many of those workgroups, so the
+    verifying passes leave work and the chained last pass has to end the ripple.  Product geometry
+    (64-Kbit workgroups) practically never gets there."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "libkpeg_amd", "libkpeg_hip_stress.so")
+    assert os.path.exists(lib), "run libkpeg_amd.build.build_all()"
+    env = dict(os.environ, KPEG_HIP_LIB=lib)
+    out = subprocess.run([sys.executable, "-c", _STRESS % {"tests": os.path.join(root, "tests"), "root": root}], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    passes = int(out.stdout.strip().split("PASSES")[-1])
+    assert passes >= 4, "the stress geometry no longer reaches the chained pass (passes=%d)" % passes
+
+
+def test_dense_noise_stream(ctx):
+    """Dense noise at q95 over ~190 workgroups: long codes, slow re-synchronisation."""
+    data = T.synth_jpeg(1024, 512, seed=21, quality=95, sigma=0.0, mode=1)
+    st, want = T.oracle_decode(data)
+    assert st == T.DECODE_DONE
+    p = T.oracle_parse(data)
     got = ctx.decode_scan(T.make_frame(p), p.scan)
     bad = np.argwhere(got != want)
     assert bad.size == 0, "first mismatches (y,x,c): %s of %d" % (bad[:8].tolist(), len(bad))
