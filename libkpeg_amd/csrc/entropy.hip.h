@@ -51,12 +51,12 @@ namespace kpeg_dev {
 #define KPEG_SYNC_STATS 0   // 1: loop counts into status words 8..13 (tools/sync_dbg.py)
 #endif
 #ifndef KPEG_SUBSEQ_BITS
-#define KPEG_SUBSEQ_BITS 128
+#define KPEG_SUBSEQ_BITS 96
 #endif
 #ifndef KPEG_SYNC_WG
 #define KPEG_SYNC_WG 512
 #endif
-constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable: 64, 128, 256, 512)
+constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable multiple of 32 >= 64; 96 measured best on the 8K workload)
 constexpr int SUBSEQ_WORDS = SUBSEQ_BITS / 32;
 constexpr int SYNC_WG = KPEG_SYNC_WG;          // threads per workgroup of K1 and K2
 constexpr int SYNC_PASSES = 4;   // sync kernels enqueued per call: pass 0, the verifying pass 1, boundary passes (idle ones exit at once)
