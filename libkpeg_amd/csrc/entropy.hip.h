@@ -184,7 +184,8 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
 
 struct EntropyScratch {
     void* d_u = nullptr;        size_t u_cap = 0;       // un-stuffed words
-    void* d_part = nullptr;     size_t part_cap = 0;    // per-block partial sums of K0
+    void* d_part = nullptr;     size_t part_cap = 0;    // K0's look-back words, one per 4 KiB of scan
+    bool part_clean = false;    // d_part is all zero (k_scan_wsum of the previous call cleared what that call used)
     void* d_segoff = nullptr;   size_t seg_cap = 0;     // seg_off[S+1], sub_base[S+1]
     void* d_state = nullptr;    size_t state_cap = 0;   // X[nsub], Xb[2][nwg], assumed[nwg] uint64
     void* d_cnt = nullptr;      size_t cnt_cap = 0;     // cnt[nsub] int4, prefix[nsub] int4
@@ -253,70 +254,21 @@ __device__ __forceinline__ void us_flags(const uint8_t* b, uint32_t n, uint32_t 
     }
 }
 
-__global__ __launch_bounds__(US_THREADS) void k_unstuff_count(const uint8_t* b, uint32_t n, int rst, uint2* part)
-{
-    __shared__ uint32_t s_k[US_THREADS / 64], s_m[US_THREADS / 64];
-    uint32_t j0 = (blockIdx.x * US_THREADS + threadIdx.x) * US_BYTES_PER_THREAD;
-    uint32_t km, mm;
-    us_flags(b, n, j0, rst != 0, km, mm);
-    uint32_t k = __popc(km), m = __popc(mm);
-    for (int o = 32; o > 0; o >>= 1) {
-        k += __shfl_down(k, o);
-        m += __shfl_down(m, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_k[threadIdx.x >> 6] = k;
-        s_m[threadIdx.x >> 6] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tk = 0, tm = 0;
-        for (int i = 0; i < US_THREADS / 64; ++i) {
-            tk += s_k[i];
-            tm += s_m[i];
-        }
-        part[blockIdx.x] = make_uint2(tk, tm);
-    }
-}
-
-// single workgroup: exclusive scan of part[] in place, totals to meta
-__global__ __launch_bounds__(1024) void k_unstuff_scan(uint2* part, uint32_t nparts, EntropyMeta* meta)
-{
-    __shared__ uint2 s[1024];
-    __shared__ uint2 carry;
-    if (threadIdx.x == 0) carry = make_uint2(0, 0);
-    __syncthreads();
-    for (uint32_t base = 0; base < nparts; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint2 v = i < nparts ? part[i] : make_uint2(0, 0);
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            uint2 t = make_uint2(0, 0);
-            if ((int)threadIdx.x >= o) t = s[threadIdx.x - o];
-            __syncthreads();
-            s[threadIdx.x].x += t.x;
-            s[threadIdx.x].y += t.y;
-            __syncthreads();
-        }
-        uint2 incl = s[threadIdx.x];
-        uint2 c = carry;
-        if (i < nparts) part[i] = make_uint2(c.x + incl.x - v.x, c.y + incl.y - v.y);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = make_uint2(c.x + incl.x, c.y + incl.y);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        meta->n_u = carry.x;
-        meta->nseg = carry.y + 1;
-    }
-}
-
-__global__ __launch_bounds__(US_THREADS) void k_unstuff_scatter(const uint8_t* b, uint32_t n, int rst, const uint2* part,
-                                                                uint8_t* u, uint32_t* seg_off, uint32_t seg_cap)
+// One launch: every workgroup flags its 4 KiB, scans its keep/marker counts, gets its base from its
+// predecessors by decoupled look-back (aggregate / inclusive prefix published in one 64-bit word:
+// kept bytes [27:0], markers [54:28], state [63:62]; workgroups are dispatched in index order), then
+// scatters.  The last workgroup knows the totals; without restart markers it also does k_seg_setup's
+// job (one segment), which saves that launch.  part[] must be zero on entry: k_scan_wsum clears it
+// for the next call.
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_PFX = 2ull << 62;
+__global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
+                                                        uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
+                                                        uint32_t nsub_cap, uint32_t* status)
 {
     __shared__ uint32_t s_k[US_THREADS], s_m[US_THREADS];
-    uint32_t j0 = (blockIdx.x * US_THREADS + threadIdx.x) * US_BYTES_PER_THREAD;
+    __shared__ uint32_t s_base[2];
+    const uint32_t g = blockIdx.x;
+    uint32_t j0 = (g * US_THREADS + threadIdx.x) * US_BYTES_PER_THREAD;
     uint32_t km, mm;
     us_flags(b, n, j0, rst != 0, km, mm);
     s_k[threadIdx.x] = __popc(km);
@@ -334,9 +286,39 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff_scatter(const uint8_t* b
         s_m[threadIdx.x] += c;
         __syncthreads();
     }
-    uint2 base = part[blockIdx.x];
-    uint32_t pos = base.x + s_k[threadIdx.x] - __popc(km);
-    uint32_t mk = base.y + s_m[threadIdx.x] - __popc(mm);
+    if (threadIdx.x < 64) {
+        // wavefront 0 looks back 64 predecessors at a time: the nearest inclusive prefix ends the walk
+        const uint32_t lane = threadIdx.x;
+        const unsigned long long mine = (unsigned long long)s_k[US_THREADS - 1] | ((unsigned long long)s_m[US_THREADS - 1] << 28);
+        if (lane == 0 && g > 0) __hip_atomic_store(&part[g], mine | LB_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t acc_k = 0, acc_m = 0;
+        for (int base = (int)g - 1; base >= 0; base -= 64) {
+            const int j = base - (int)lane;
+            unsigned long long v = LB_PFX;   // before the first workgroup: prefix 0
+            if (j >= 0)
+                while (((v = __hip_atomic_load(&part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+            const unsigned long long pfx = __ballot((v >> 62) == 2);
+            const uint32_t first = pfx ? (uint32_t)__builtin_ctzll(pfx) : 63u;
+            uint32_t k = lane <= first ? (uint32_t)(v & 0xFFFFFFFu) : 0u;
+            uint32_t m = lane <= first ? (uint32_t)((v >> 28) & 0x7FFFFFFu) : 0u;
+            for (int o = 32; o > 0; o >>= 1) {
+                k += __shfl_down(k, o);
+                m += __shfl_down(m, o);
+            }
+            acc_k += k;
+            acc_m += m;
+            if (pfx) break;
+        }
+        if (lane == 0) {
+            const unsigned long long acc = (unsigned long long)acc_k | ((unsigned long long)acc_m << 28);
+            __hip_atomic_store(&part[g], (acc + mine) | LB_PFX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base[0] = acc_k;
+            s_base[1] = acc_m;
+        }
+    }
+    __syncthreads();
+    uint32_t pos = s_base[0] + s_k[threadIdx.x] - __popc(km);
+    uint32_t mk = s_base[1] + s_m[threadIdx.x] - __popc(mm);
     for (int k = 0; k < US_BYTES_PER_THREAD; ++k) {
         uint32_t j = j0 + k;
         if (j >= n) break;
@@ -349,7 +331,32 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff_scatter(const uint8_t* b
             pos++;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) seg_off[0] = 0;
+    if (g == 0 && threadIdx.x == 0) seg_off[0] = 0;
+    if (g == gridDim.x - 1) {
+        const uint32_t n_u = s_base[0] + s_k[US_THREADS - 1], nseg = s_base[1] + s_m[US_THREADS - 1] + 1;
+        if (threadIdx.x == 0) {
+            meta->n_u = n_u;
+            meta->nseg = nseg;
+        }
+        if (!rst) {
+            // one segment: what k_seg_setup does.  Bytes past the end read as zero (the readers look ahead).
+            if (threadIdx.x < 16) u[(n_u + threadIdx.x) ^ 3] = 0;
+            if (threadIdx.x == 0) {
+                uint32_t nsub = (n_u * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
+                if (nsub == 0) nsub = 1;
+                seg_off[1] = n_u;
+                sub_base[0] = 0;
+                sub_base[1] = nsub;
+                if (nsub > nsub_cap) {
+                    atomicOr(&status[1], 2u);
+                    nsub = 0;
+                }
+                meta->nsub = nsub;
+                for (int i = 0; i < SYNC_PASSES + 8; ++i) meta->moved[i] = 0;
+                meta->total_blocks = 0;
+            }
+        }
+    }
 }
 
 // single workgroup: seg_off[nseg] = n_u, zero the padding words, sub_base[] = exclusive scan
@@ -917,8 +924,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 
 // ------------------------------------------------------------------------------------------
 // scan of (nb, dc0, dc1, dc2): workgroup totals -> exclusive prefix (single workgroup)
-__global__ __launch_bounds__(1024) void k_scan_wsum(int4* wsum, EntropyMeta* meta, uint32_t* status, int last_pass)
+__global__ __launch_bounds__(1024) void k_scan_wsum(int4* wsum, EntropyMeta* meta, uint32_t* status, int last_pass,
+                                                    unsigned long long* part, uint32_t nparts)
 {
+    for (uint32_t i = threadIdx.x; i < nparts; i += 1024) part[i] = 0ull;   // K0's look-back words, for the next call
     __shared__ int4 s[1024];
     __shared__ int4 carry;
     const uint32_t nsub = meta->nsub;
@@ -1286,7 +1295,11 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     const uint32_t nwg_cap = (nsub_cap + OWN - 1) / OWN;
     int rc;
     if ((rc = ent_grow(&S->d_u, &S->u_cap, (size_t)n + 64, L.stream, err))) return rc;
-    if ((rc = ent_grow(&S->d_part, &S->part_cap, (size_t)nparts * sizeof(uint2), L.stream, err))) return rc;
+    {
+        void* const before = S->d_part;
+        if ((rc = ent_grow(&S->d_part, &S->part_cap, (size_t)nparts * sizeof(unsigned long long), L.stream, err))) return rc;
+        if (S->d_part != before) S->part_clean = false;
+    }
     if ((rc = ent_grow(&S->d_segoff, &S->seg_cap, (size_t)seg_cap * 2 * sizeof(uint32_t), L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 5 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 32, L.stream, err))) return rc;
@@ -1312,12 +1325,13 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     int4* prefix = cnt + nsub_cap;
     const int rst = L.restart_interval ? 1 : 0;
 
-    hipLaunchKernelGGL(k_unstuff_count, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, rst, (uint2*)S->d_part);
-    hipLaunchKernelGGL(k_unstuff_scan, dim3(1), dim3(1024), 0, L.stream, (uint2*)S->d_part, nparts, S->d_meta);
-    hipLaunchKernelGGL(k_unstuff_scatter, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, rst, (const uint2*)S->d_part,
-                       (uint8_t*)S->d_u, seg_off, seg_cap);
-    hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, L.stream, S->d_meta, seg_off, sub_base, seg_cap, nsub_cap,
-                       (uint8_t*)S->d_u, nseg_expected, L.d_status);
+    if (!S->part_clean) ENT_HIP(hipMemsetAsync(S->d_part, 0, S->part_cap, L.stream));
+    S->part_clean = false;
+    hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, rst, (unsigned long long*)S->d_part,
+                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status);
+    if (rst)
+        hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, L.stream, S->d_meta, seg_off, sub_base, seg_cap, nsub_cap,
+                           (uint8_t*)S->d_u, nseg_expected, L.d_status);
     mark(1);
 
     SyncArgs sa;
@@ -1348,7 +1362,8 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     }
     mark(2);
 
-    hipLaunchKernelGGL(k_scan_wsum, dim3(1), dim3(1024), 0, L.stream, (int4*)S->d_wsum, S->d_meta, L.d_status, npass - 1);
+    hipLaunchKernelGGL(k_scan_wsum, dim3(1), dim3(1024), 0, L.stream, (int4*)S->d_wsum, S->d_meta, L.d_status, npass - 1,
+                       (unsigned long long*)S->d_part, nparts);
     if (rst)
         hipLaunchKernelGGL(k_scan_apply, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, (const int4*)cnt, (const int4*)S->d_wsum,
                            (const EntropyMeta*)S->d_meta, prefix);
@@ -1375,6 +1390,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     mark(4);
     mark(5);
     ENT_HIP(hipGetLastError());
+    S->part_clean = true;   // k_scan_wsum is enqueued
     return KPEG_HIP_OK;
 #undef ENT_HIP
 }
