@@ -59,7 +59,7 @@ namespace kpeg_dev {
 constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable multiple of 32 >= 64; 96 measured best on the 8K workload)
 constexpr int SUBSEQ_WORDS = SUBSEQ_BITS / 32;
 constexpr int SYNC_WG = KPEG_SYNC_WG;          // threads per workgroup of K1 and K2
-constexpr int SYNC_PASSES = 4;   // sync kernels enqueued per call: pass 0, the verifying pass 1, boundary passes (idle ones exit at once)
+constexpr int SYNC_PASSES = 3;   // sync kernels enqueued per call: pass 0, the verifying pass 1, the chained pass (+ scan of the totals)
 #ifndef KPEG_WARM_BITS
 #define KPEG_WARM_BITS 1024
 #endif
@@ -180,12 +180,13 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t nsub;     // total sub-sequences
     uint32_t moved[SYNC_PASSES + 8];  // per pass >= 1: workgroups whose last exit state moved
     uint32_t total_blocks;
+    uint32_t ticket;   // workgroups that have finished the chained pass
 };
 
 struct EntropyScratch {
     void* d_u = nullptr;        size_t u_cap = 0;       // un-stuffed words
     void* d_part = nullptr;     size_t part_cap = 0;    // K0's look-back words, one per 4 KiB of scan
-    bool part_clean = false;    // d_part is all zero (k_scan_wsum of the previous call cleared what that call used)
+    bool part_clean = false;    // d_part is all zero (the previous call's last K1 launch cleared what that call used)
     void* d_segoff = nullptr;   size_t seg_cap = 0;     // seg_off[S+1], sub_base[S+1]
     void* d_state = nullptr;    size_t state_cap = 0;   // X[nsub], Xb[2][nwg], assumed[nwg] uint64
     void* d_cnt = nullptr;      size_t cnt_cap = 0;     // cnt[nsub] int4, prefix[nsub] int4
@@ -258,8 +259,8 @@ __device__ __forceinline__ void us_flags(const uint8_t* b, uint32_t n, uint32_t 
 // predecessors by decoupled look-back (aggregate / inclusive prefix published in one 64-bit word:
 // kept bytes [27:0], markers [54:28], state [63:62]; workgroups are dispatched in index order), then
 // scatters.  The last workgroup knows the totals; without restart markers it also does k_seg_setup's
-// job (one segment), which saves that launch.  part[] must be zero on entry: k_scan_wsum clears it
-// for the next call.
+// job (one segment), which saves that launch.  part[] must be zero on entry: K1's last launch clears
+// it for the next call.
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PFX = 2ull << 62;
 __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
                                                         uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
                 meta->nsub = nsub;
                 for (int i = 0; i < SYNC_PASSES + 8; ++i) meta->moved[i] = 0;
                 meta->total_blocks = 0;
+                meta->ticket = 0;
             }
         }
     }
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(1024) void k_seg_setup(EntropyMeta* meta, uint32_t*
         }
         for (int i = 0; i < SYNC_PASSES + 8; ++i) meta->moved[i] = 0;
         meta->total_blocks = 0;
+        meta->ticket = 0;
     }
 }
 
@@ -675,6 +678,8 @@ struct SyncArgs {
     uint32_t* done;     // [nwg_cap] chained pass: workgroup g has published its final exit state
     int chained;        // this pass waits for the predecessor workgroup instead of trusting the previous pass
     uint32_t warm;      // warm-up sub-sequences (<= WARM)
+    unsigned long long* part;   // K0's look-back words (cleared by the last launch)
+    uint32_t nparts;
     uint32_t nwg_cap;
     int pass;
     uint32_t* status;   // KPEG_SYNC_STATS builds only: words 8..13 collect loop counts
@@ -691,6 +696,50 @@ __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list,
     base = (uint32_t)__shfl((int)base, 0);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
     if (want) list[base + rank] = (uint16_t)v;
+}
+
+// Scan of (nb, dc0, dc1, dc2): workgroup totals -> exclusive prefix, by one workgroup of K1's last
+// launch (SYNC_WG threads; s = SYNC_WG int4 of LDS); also the call's bookkeeping: blocks found, passes
+// used, K0's look-back words cleared for the next call.
+__device__ void wsum_scan(int4* wsum, EntropyMeta* meta, uint32_t* status, int pass, bool rippling, unsigned long long* part,
+                          uint32_t nparts, int4* s, int4* carry)
+{
+    const uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < nparts; i += SYNC_WG) part[i] = 0ull;
+    const uint32_t nw = (meta->nsub + OWN - 1) / OWN;
+    if (t == 0) *carry = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    for (uint32_t base = 0; base < nw; base += SYNC_WG) {
+        const uint32_t i = base + t;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (i < nw) {
+            // written by other workgroups of this launch: read past this CU's L1
+            int* w = reinterpret_cast<int*>(wsum + i);
+            v = make_int4(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                          __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        s[t] = v;
+        __syncthreads();
+        for (int o = 1; o < SYNC_WG; o <<= 1) {
+            int4 x = make_int4(0, 0, 0, 0);
+            if ((int)t >= o) x = s[t - o];
+            __syncthreads();
+            s[t] = add4(s[t], x);
+            __syncthreads();
+        }
+        const int4 incl = s[t], c = *carry;
+        if (i < nw) wsum[i] = make_int4(c.x + incl.x - v.x, c.y + incl.y - v.y, c.z + incl.z - v.z, c.w + incl.w - v.w);
+        __syncthreads();
+        if (t == SYNC_WG - 1) *carry = add4(c, incl);
+        __syncthreads();
+    }
+    if (t == 0) {
+        meta->total_blocks = (uint32_t)carry->x;
+        uint32_t passes = 1;   // launches of K1 that had work
+        for (int q = 1; q < pass; ++q)
+            if (q == 1 || meta->moved[q - 1]) passes = q + 1;
+        status[2] = rippling ? (uint32_t)pass + 1 : passes;
+    }
 }
 
 // Items of a workgroup: [0, wu) the last wu sub-sequences of its predecessor (warm-up, pass 0 only),
@@ -717,8 +766,24 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     const uint32_t g = blockIdx.x, t = threadIdx.x;
     const uint32_t nsub = a.meta->nsub;
     const uint32_t i0 = g * OWN;
+    // The last launch (chained) also scans the workgroup totals: at once by workgroup 0 if the pass
+    // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
+    const bool rippling = p >= 2 && a.meta->moved[p - 1] != 0;
+    if (a.chained && !rippling) {
+        if (g == 0) wsum_scan(a.wsum, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
+        return;
+    }
     if (i0 >= nsub) return;
-    if (p >= 2 && a.meta->moved[p - 1] == 0) return;  // converged
+    if (p >= 2 && !rippling) return;  // converged
+    auto finish_chained = [&]() {
+        // whole workgroup: count this workgroup as done; the last one scans
+        if (t == 0) {
+            __threadfence();
+            s_n[0] = atomicAdd(&a.meta->ticket, 1u) == (nsub + OWN - 1) / OWN - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_n[0]) wsum_scan(a.wsum, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
+    };
     const uint64_t* Xb_prev = a.Xb + (size_t)((p & 1) ^ 1) * a.nwg_cap;
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
     // Chained pass (the last one enqueued, only if the pass before it still moved something): every
@@ -747,6 +812,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                     __hip_atomic_store(&a.done[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            if (a.chained) finish_chained();
             return;
         }
     }
@@ -920,48 +986,13 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             atomicAdd(&a.meta->moved[p], 1u);
         }
     }
+    if (a.chained) {
+        __syncthreads();
+        finish_chained();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// scan of (nb, dc0, dc1, dc2): workgroup totals -> exclusive prefix (single workgroup)
-__global__ __launch_bounds__(1024) void k_scan_wsum(int4* wsum, EntropyMeta* meta, uint32_t* status, int last_pass,
-                                                    unsigned long long* part, uint32_t nparts)
-{
-    for (uint32_t i = threadIdx.x; i < nparts; i += 1024) part[i] = 0ull;   // K0's look-back words, for the next call
-    __shared__ int4 s[1024];
-    __shared__ int4 carry;
-    const uint32_t nsub = meta->nsub;
-    const uint32_t nw = (nsub + OWN - 1) / OWN;
-    if (threadIdx.x == 0) carry = make_int4(0, 0, 0, 0);
-    __syncthreads();
-    for (uint32_t base = 0; base < nw; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        int4 v = i < nw ? wsum[i] : make_int4(0, 0, 0, 0);
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int4 t = make_int4(0, 0, 0, 0);
-            if ((int)threadIdx.x >= o) t = s[threadIdx.x - o];
-            __syncthreads();
-            s[threadIdx.x] = add4(s[threadIdx.x], t);
-            __syncthreads();
-        }
-        int4 incl = s[threadIdx.x], c = carry;
-        if (i < nw) wsum[i] = make_int4(c.x + incl.x - v.x, c.y + incl.y - v.y, c.z + incl.z - v.z, c.w + incl.w - v.w);
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = add4(c, incl);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        meta->total_blocks = (uint32_t)carry.x;
-        uint32_t passes = 1;
-        for (int t = 1; t <= last_pass; ++t)
-            if (t == 1 || meta->moved[t - 1]) passes = t + 1;
-        status[2] = passes;
-        if (meta->moved[last_pass] != 0) atomicOr(&status[1], 4u);  // not converged within the enqueued passes
-    }
-}
-
 // materialised exclusive prefix (only needed when restart segments re-base it)
 __global__ __launch_bounds__(SYNC_WG) void k_scan_apply(const int4* cnt, const int4* wsum, const EntropyMeta* meta, int4* prefix)
 {
@@ -1354,16 +1385,16 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     sa.warm = L.warm < 0 ? (uint32_t)WARM : min((uint32_t)L.warm, (uint32_t)WARM);
     sa.nwg_cap = nwg_cap;
     sa.status = L.d_status;
-    const int npass = L.sync_passes > 0 ? L.sync_passes : SYNC_PASSES;
+    const int npass = L.sync_passes >= 3 ? L.sync_passes : SYNC_PASSES;   // the last one is chained and runs the scan
+    sa.part = (unsigned long long*)S->d_part;
+    sa.nparts = nparts;
     for (int t = 0; t < npass; ++t) {
         sa.pass = t;
-        sa.chained = (t >= 2 && t == npass - 1) ? 1 : 0;
+        sa.chained = t == npass - 1 ? 1 : 0;
         hipLaunchKernelGGL(k_sync_pass, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
     }
     mark(2);
 
-    hipLaunchKernelGGL(k_scan_wsum, dim3(1), dim3(1024), 0, L.stream, (int4*)S->d_wsum, S->d_meta, L.d_status, npass - 1,
-                       (unsigned long long*)S->d_part, nparts);
     if (rst)
         hipLaunchKernelGGL(k_scan_apply, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, (const int4*)cnt, (const int4*)S->d_wsum,
                            (const EntropyMeta*)S->d_meta, prefix);
@@ -1390,7 +1421,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     mark(4);
     mark(5);
     ENT_HIP(hipGetLastError());
-    S->part_clean = true;   // k_scan_wsum is enqueued
+    S->part_clean = true;   // K1's last launch is enqueued
     return KPEG_HIP_OK;
 #undef ENT_HIP
 }

