@@ -53,10 +53,10 @@ def _synth():
     return S
 
 
-def synth_jpeg(w, h, y0=0, restart_interval=0, seed=SEED):
+def synth_jpeg(w, h, y0=0, restart_interval=0, seed=SEED, quality=QUALITY, sigma=SIGMA, mode=0):
     cap = w * h * 3 + (w * h) // 2 + 65536
     buf = np.empty(cap, np.uint8)
-    n = _synth().kpeg_synth_jpeg_rows(w, h, y0, seed, QUALITY, restart_interval, SIGMA, 0, buf.ctypes.data, cap)
+    n = _synth().kpeg_synth_jpeg_rows(w, h, y0, seed, quality, restart_interval, sigma, mode, buf.ctypes.data, cap)
     assert n > 0
     return buf[:n].tobytes()
 
@@ -214,6 +214,39 @@ def main():
     ctx.set_profiling(False)
     tm = {k: v / nprof for k, v in acc.items()}
 
+    # ---- SURVEY 8(d) side figures (single GPU, default workload): device-copy ceiling and the dense stress input
+    copy_gbs = stress = None
+    if world == 1 and not args.idct_only and (W, H) == (W8K, H8K):
+        a = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(20):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        copy_gbs = 2 * a.numel() * 20 / (time.perf_counter() - c0) / 1e9   # read + write
+        del a, b
+        sw, sh = 1920, 1080
+        sdata = synth_jpeg(sw, sh, quality=95, sigma=0.0, mode=1)   # dense uniform noise, q95: long codes, slow re-synchronisation
+        src, sframe, sscan = K.host_parse(sdata)
+        assert src == K.DECODE_DONE, src
+        sd_scan = torch.from_numpy(np.ascontiguousarray(sscan)).cuda()
+        sd_rgb = torch.empty((sh, sw, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            ctx.decode_stripe_dev(sframe, sd_scan.data_ptr(), sd_scan.numel(), 0, sh // 8, sd_rgb.data_ptr())
+        ctx.sync()
+        s0 = time.perf_counter()
+        for _ in range(20):
+            ctx.decode_stripe_dev(sframe, sd_scan.data_ptr(), sd_scan.numel(), 0, sh // 8, sd_rgb.data_ptr())
+        torch.cuda.synchronize()
+        sms = (time.perf_counter() - s0) / 20 * 1e3
+        ctx.sync()
+        stress = {"workload": "%dx%d dense uniform noise, q95 (every coefficient non-zero, every pixel on K4's exact path)" % (sw, sh),
+                  "scan_bytes": int(sd_scan.numel()), "ms_per_step": round(sms, 4), "value": round(sw * sh / (sms * 1e-3) / 1e6, 2),
+                  "unit": "Mpixels/s"}
+
     # ---- gather of the stripes to rank 0 (the path's one exchange step), timed apart ----------
     gather = None
     if world > 1 and not args.no_gather:
@@ -260,6 +293,8 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (idct_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if idct_ms > 0 else None,
                 "traffic": traffic, "kernel": "k_idct_colour_fast", "kernel_ms": round(idct_ms, 5),
                 "algorithmic_bytes": int(alg_bytes)}
+        if copy_gbs:
+            roof["device_copy_GBs"] = round(copy_gbs, 1)   # measured ceiling: 256 MiB device-to-device copy, read + write bytes
         out = {
             "metric": "Mpixels/s decoded (JFIF->RGB) + achieved HBM GB/s, 8K 4:4:4 baseline",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -275,6 +310,8 @@ def main():
             "kernels_ms": {k: round(v, 5) for k, v in tm.items() if k.endswith("_ms")},
             "sync_passes": tm.get("sync_rounds"), "exact_pixels_per_image": tm.get("exact_pixels"),
         }
+        if stress:
+            out["stress"] = stress
         if gather:
             out["gather"] = gather
             out["value_incl_gather"] = round(pixels_per_step / ((ms_per_step + gather["ms"]) * 1e-3) / 1e6, 2)

@@ -275,20 +275,36 @@ constexpr int QUEUE_CAP = 256;                  // queued pixels per tile; more 
 constexpr int K4_WAVES_PER_CU = 4 * KPEG_K4_OCC;  // one wavefront per workgroup, KPEG_K4_OCC per SIMD
 
 // 1-D 8-point inverse DCT kernel sum_v a[v] cos((2y+1) v pi/16), y = 0..7, in place.
+// NV < 8: a[NV..7] are known to be zero and their terms are left out.  fma(0, c, x) == x and
+// x + 0 == x exactly, so the pruned forms return the same floats as the full one (tools/idct_bound.py
+// analyses the full sequence; its bound covers them).
+template <int NV>
 __device__ __forceinline__ void row_idct8(float a[8])
 {
     const float c1 = 0.98078528040323044913f, c2 = 0.92387953251128675613f, c3 = 0.83146961230254523708f,
                 c4 = 0.70710678118654752440f, c5 = 0.55557023301960222474f, c6 = 0.38268343236508977173f,
                 c7 = 0.19509032201612826785f;
-    float t0 = __builtin_fmaf(a[4], c4, a[0]);
-    float t1 = __builtin_fmaf(a[4], -c4, a[0]);
-    float p = __builtin_fmaf(a[6], c6, a[2] * c2);
-    float q = __builtin_fmaf(a[6], -c2, a[2] * c6);
+    float t0 = NV > 4 ? __builtin_fmaf(a[4], c4, a[0]) : a[0];
+    float t1 = NV > 4 ? __builtin_fmaf(a[4], -c4, a[0]) : a[0];
+    float p = NV > 6 ? __builtin_fmaf(a[6], c6, a[2] * c2) : a[2] * c2;
+    float q = NV > 6 ? __builtin_fmaf(a[6], -c2, a[2] * c6) : a[2] * c6;
     float e0 = t0 + p, e3 = t0 - p, e1 = t1 + q, e2 = t1 - q;
-    float o0 = __builtin_fmaf(a[7], c7, __builtin_fmaf(a[5], c5, __builtin_fmaf(a[3], c3, a[1] * c1)));
-    float o1 = __builtin_fmaf(a[7], -c5, __builtin_fmaf(a[5], -c1, __builtin_fmaf(a[3], -c7, a[1] * c3)));
-    float o2 = __builtin_fmaf(a[7], c3, __builtin_fmaf(a[5], c7, __builtin_fmaf(a[3], -c1, a[1] * c5)));
-    float o3 = __builtin_fmaf(a[7], -c1, __builtin_fmaf(a[5], c3, __builtin_fmaf(a[3], -c5, a[1] * c7)));
+    float o0 = __builtin_fmaf(a[3], c3, a[1] * c1);
+    float o1 = __builtin_fmaf(a[3], -c7, a[1] * c3);
+    float o2 = __builtin_fmaf(a[3], -c1, a[1] * c5);
+    float o3 = __builtin_fmaf(a[3], -c5, a[1] * c7);
+    if (NV > 5) {
+        o0 = __builtin_fmaf(a[5], c5, o0);
+        o1 = __builtin_fmaf(a[5], -c1, o1);
+        o2 = __builtin_fmaf(a[5], c7, o2);
+        o3 = __builtin_fmaf(a[5], c3, o3);
+    }
+    if (NV > 7) {
+        o0 = __builtin_fmaf(a[7], c7, o0);
+        o1 = __builtin_fmaf(a[7], -c5, o1);
+        o2 = __builtin_fmaf(a[7], c3, o2);
+        o3 = __builtin_fmaf(a[7], -c1, o3);
+    }
     a[0] = e0 + o0;
     a[7] = e0 - o0;
     a[1] = e1 + o1;
@@ -306,6 +322,9 @@ __device__ __forceinline__ void row_idct8(float a[8])
 // combines the two halves: out = own + mirror * s.
 // Hazard (VALU write -> DPP read of the same VGPR needs 2 wait states): the leading s_nop covers
 // the compiler-produced g; inside, every DPP read is >= 8 instructions behind its producer.
+// NU < 8: coefficient rows NU..7 are zero in every block of the wavefront, i.e. g == 0 on the lanes
+// that hold them; their broadcast terms (quad lanes NU/2..3) are left out: fmac(acc, 0, k) == acc.
+template <int NU>
 __device__ __forceinline__ void column_idct8(const float g[8], float k0, float k1, float k2, float k3, float s, float o[8])
 {
 #define KPEG_DPP8(op, sel, kreg)                                                                    \
@@ -317,6 +336,7 @@ __device__ __forceinline__ void column_idct8(const float g[8], float k0, float k
     op " %5, %13, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                  \
     op " %6, %14, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"                                  \
     op " %7, %15, " kreg " " sel " row_mask:0xf bank_mask:0xf\n\t"
+    if (NU > 6) {
     asm("s_nop 1\n\t"
         KPEG_DPP8("v_mul_f32_dpp", "quad_perm:[0,0,0,0]", "%16")
         KPEG_DPP8("v_fmac_f32_dpp", "quad_perm:[1,1,1,1]", "%17")
@@ -334,6 +354,40 @@ __device__ __forceinline__ void column_idct8(const float g[8], float k0, float k
         : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
         : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(k0), "v"(k1),
           "v"(k2), "v"(k3), "v"(s));
+    } else if (NU > 4) {
+    asm("s_nop 1\n\t"
+        KPEG_DPP8("v_mul_f32_dpp", "quad_perm:[0,0,0,0]", "%16")
+        KPEG_DPP8("v_fmac_f32_dpp", "quad_perm:[1,1,1,1]", "%17")
+        KPEG_DPP8("v_fmac_f32_dpp", "quad_perm:[2,2,2,2]", "%18")
+        "v_fmac_f32_dpp %0, %0, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(k0), "v"(k1),
+          "v"(k2), "v"(k3), "v"(s));
+    } else {
+    asm("s_nop 1\n\t"
+        KPEG_DPP8("v_mul_f32_dpp", "quad_perm:[0,0,0,0]", "%16")
+        KPEG_DPP8("v_fmac_f32_dpp", "quad_perm:[1,1,1,1]", "%17")
+        "v_fmac_f32_dpp %0, %0, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(k0), "v"(k1),
+          "v"(k2), "v"(k3), "v"(s));
+    }
 #undef KPEG_DPP8
 }
 
@@ -362,28 +416,36 @@ struct LaneConst {
 
 // One component block: d = 8 int16 (row u of the block, this lane's share).
 // out[i] = fast value of sample i of pixel row (lane & 7).
+// N < 8: the block's coefficients outside its top-left N x N corner are zero, for every block this
+// wavefront holds of this component (wave-uniform choice: see the caller).
+template <int N>
 __device__ __forceinline__ void block_fast(const uint4 d, const LaneConst& lc, const float* __restrict__ m, int tab, float out[8])
 {
     const uint32_t w[4] = {d.x, d.y, d.z, d.w};
     float a[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        a[2 * i] = (float)(short)(w[i] & 0xFFFF);
-        a[2 * i + 1] = (float)((int)w[i] >> 16);
+        a[2 * i] = 2 * i < N ? (float)(short)(w[i] & 0xFFFF) : 0.0f;
+        a[2 * i + 1] = 2 * i + 1 < N ? (float)((int)w[i] >> 16) : 0.0f;
     }
     // column 0 through the reference's own chain 0.25 * (cc * (float)(c*Q)): exact for the DC term
     a[0] = 0.25f * (lc.cc0 * (a[0] * lc.q0[tab]));
     // AC input scale 0.25 * cc[u][v] * Q[u][v] of this lane's row, from LDS (m[0] unused)
-    const float4 mlo = *reinterpret_cast<const float4*>(m), mhi = *reinterpret_cast<const float4*>(m + 4);
+    const float4 mlo = *reinterpret_cast<const float4*>(m);
     a[1] *= mlo.y;
     a[2] *= mlo.z;
     a[3] *= mlo.w;
-    a[4] *= mhi.x;
-    a[5] *= mhi.y;
-    a[6] *= mhi.z;
-    a[7] *= mhi.w;
-    row_idct8(a);
-    column_idct8(a, lc.k[0], lc.k[1], lc.k[2], lc.k[3], lc.s, out);
+    if (N > 4) {
+        const float4 mhi = *reinterpret_cast<const float4*>(m + 4);
+        a[4] *= mhi.x;
+        a[5] *= mhi.y;
+        if (N > 6) {
+            a[6] *= mhi.z;
+            a[7] *= mhi.w;
+        }
+    }
+    row_idct8<N>(a);
+    column_idct8<N>(a, lc.k[0], lc.k[1], lc.k[2], lc.k[3], lc.s, out);
 }
 
 __device__ __forceinline__ uint32_t tile_row(const IdctParams& p, uint32_t tile)
@@ -565,9 +627,15 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             v[2][i] = __uint_as_float(d2.z + i) * 1e-30f;
         }
 #else
-        block_fast(d0, lc, &s_m[0][u * 8], 0, v[0]);
-        block_fast(d1, lc, &s_m[1][u * 8], 1, v[1]);
-        block_fast(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        // Quantised high frequencies are mostly zero: if no block of this wavefront has a coefficient outside
+        // its top-left 6x6 (luma) / 4x4 (chroma) corner, the terms of the empty rows and columns are left out
+        // (same floats as the full transform, see row_idct8).  8K q75: luma 6x6 for 98 % of the tiles, chroma 4x4 for 99 %.
+        if (__ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0)) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        else block_fast<6>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        if (__ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0)) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        else block_fast<4>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        else block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
 #endif
         const float thr0 = 0.5f - fabsf(e0), thr1 = 0.5f - fabsf(e1), thr2 = 0.5f - fabsf(e2);
         const bool sp0 = __float_as_uint(e0) >> 31, sp1 = __float_as_uint(e1) >> 31, sp2 = __float_as_uint(e2) >> 31;
