@@ -101,6 +101,54 @@ def cpu_baseline(sample_w=2560, sample_h=1440):
             "sample": sample + "; oracle/kpeg_oracle.c (cos table precomputed, zero terms skipped), 1 thread"}
 
 
+def bench_batch(args, torch, K):
+    """BASELINE config 4 (throughput mode): a batch of independent 1080p images resident in HBM."""
+    n, w, h = args.batch, 1920, 1080
+    uniq = min(n, 32)   # distinct images (host-side synthesis takes ~0.1 s each); the batch cycles through them
+    frames, scans = None, []
+    for i in range(uniq):
+        rc, frame, scan = K.host_parse(synth_jpeg(w, h, seed=SEED + i))
+        assert rc == K.DECODE_DONE, rc
+        frames = frame
+        scans.append(torch.from_numpy(np.ascontiguousarray(scan)).cuda())
+    d_scans = [scans[i % uniq] for i in range(n)]
+    d_rgbs = [torch.empty((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    ctx = K.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    sp, sl, op = [t.data_ptr() for t in d_scans], [t.numel() for t in d_scans], [t.data_ptr() for t in d_rgbs]
+
+    def lanes():
+        ctx.decode_batch_dev(frames, sp, sl, op)
+
+    def one_stream():
+        for i in range(n):
+            ctx.decode_scan_dev(frames, sp[i], sl[i], op[i])
+
+    res = {}
+    for name, fn in (("lanes", lanes), ("one_stream", one_stream)):
+        for _ in range(args.warmup):
+            fn()
+        ctx.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        ctx.sync()
+        res[name] = dt
+    mp = n * w * h / 1e6
+    print(json.dumps({
+        "metric": "Mpixels/s decoded (JFIF->RGB), batch of 1080p 4:4:4 baseline", "value": round(mp / res["lanes"], 2), "unit": "Mpixels/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["lanes"] * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "batch of %d synthetic 1920x1080 4:4:4 baseline JPEGs q%d (%d distinct, seeds %d..), resident in HBM, "
+                               "kpeg_hip_decode_batch_dev over 6 lanes" % (n, QUALITY, uniq, SEED), "images_per_step": n},
+        "images_per_s": round(n / res["lanes"], 1), "us_per_image": round(res["lanes"] / n * 1e6, 2),
+        "one_stream": {"value": round(mp / res["one_stream"], 2), "us_per_image": round(res["one_stream"] / n * 1e6, 2)},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +162,9 @@ def main():
                     help="N>1 dry run on a one-GPU box: gloo backend, every rank on cuda:0 (the driver's runs use RCCL, one GPU per rank)")
     ap.add_argument("--idct-mode", type=int, default=0, help="kpeg_hip_set_idct_mode (2 = timing experiment, wrong pixels)")
     ap.add_argument("--idct-only", action="store_true", help="time K4 alone on resident coefficients (BASELINE config 2 style)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="BASELINE config 4 instead of the headline: N synthetic 1920x1080 images (seeds 1234..), device-resident, "
+                         "kpeg_hip_decode_batch_dev (six lanes) beside the one-stream loop; one step = the whole batch")
     args = ap.parse_args()
 
     import torch
@@ -137,6 +188,9 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     coll_dev = "cpu" if args.rehearse else "cuda"
+
+    if args.batch:
+        return bench_batch(args, torch, K)
 
     W, H = args.width, args.height
     mw, mh = W // 8, H // 8

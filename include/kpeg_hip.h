@@ -111,7 +111,11 @@ int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const int16
 int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len,
                          uint8_t* rgb);
 
-/* `count` independent images of identical geometry and tables (throughput mode). */
+/* `count` independent images of identical geometry and tables (throughput mode, BASELINE config 4; the
+ * reference's counterpart is a loop over JPEGDecoder::decodeImageFile, src/main.cpp:19-33).  Images go
+ * round-robin to six internal lanes (stream + scratch each): uploads, kernels and downloads of
+ * neighbouring images overlap.  Returns after the last pixel is in rgbs[]; a stream error of any image
+ * fails the call (kpeg_hip_last_error names the lane's diagnosis). */
 int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_frame* frame, const uint8_t* const* scans,
                           const size_t* scan_lens, uint8_t* const* rgbs);
 
@@ -126,6 +130,10 @@ int kpeg_hip_decode_scan_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const u
  * mcu_rows*8 pixel rows.  One rank per GPU calls this on its stripe; the caller gathers. */
 int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* d_scan, size_t scan_len,
                                uint32_t first_mcu_row, uint32_t mcu_rows, uint8_t* d_rgb);
+/* kpeg_hip_decode_batch with device-resident scans and outputs (arrays of device pointers held on the
+ * host): asynchronous; the context's stream continues behind all lanes, errors surface at kpeg_hip_sync(). */
+int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpeg_frame* frame, const uint8_t* const* d_scans,
+                              const size_t* scan_lens, uint8_t* const* d_rgbs);
 /* Entropy decode only: d_coef receives the coefficient layout of kpeg_hip_idct_colour. */
 int kpeg_hip_entropy_decode_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* d_scan, size_t scan_len,
                                 int16_t* d_coef);

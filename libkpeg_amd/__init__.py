@@ -53,7 +53,7 @@ class Timings(ctypes.Structure):
 EXPORTS = [
     "kpeg_hip_abi_version", "kpeg_hip_create", "kpeg_hip_destroy", "kpeg_hip_strerror", "kpeg_hip_last_error",
     "kpeg_hip_set_stream", "kpeg_hip_sync", "kpeg_hip_set_profiling", "kpeg_hip_get_timings",
-    "kpeg_hip_idct_colour", "kpeg_hip_decode_scan", "kpeg_hip_decode_batch",
+    "kpeg_hip_idct_colour", "kpeg_hip_decode_scan", "kpeg_hip_decode_batch", "kpeg_hip_decode_batch_dev",
     "kpeg_hip_idct_colour_dev", "kpeg_hip_decode_scan_dev", "kpeg_hip_decode_stripe_dev",
     "kpeg_hip_entropy_decode_dev", "kpeg_hip_set_idct_mode",
 ]
@@ -94,6 +94,7 @@ def load_hip():
     L.kpeg_hip_idct_colour.argtypes = [vp, FP, vp, vp]
     L.kpeg_hip_decode_scan.argtypes = [vp, FP, vp, sz, vp]
     L.kpeg_hip_decode_batch.argtypes = [vp, c_int, FP, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp)]
+    L.kpeg_hip_decode_batch_dev.argtypes = [vp, c_int, FP, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp)]
     L.kpeg_hip_idct_colour_dev.argtypes = [vp, FP, vp, vp]
     L.kpeg_hip_decode_scan_dev.argtypes = [vp, FP, vp, sz, vp]
     L.kpeg_hip_decode_stripe_dev.argtypes = [vp, FP, vp, sz, ctypes.c_uint32, ctypes.c_uint32, vp]
@@ -161,6 +162,25 @@ class Context:
         rgb = np.empty((frame.height, frame.width, 3), np.uint8)
         self._chk(self.lib.kpeg_hip_decode_scan(self._h, ctypes.byref(frame), scan.ctypes.data, scan.size, rgb.ctypes.data))
         return rgb
+
+    def decode_batch(self, frame, scans):
+        """scans: list of byte strings / uint8 arrays of one geometry and one set of tables. Returns a list of HxWx3 uint8."""
+        n = len(scans)
+        scans = [np.frombuffer(s, dtype=np.uint8) if not isinstance(s, np.ndarray) else np.ascontiguousarray(s) for s in scans]
+        outs = [np.empty((frame.height, frame.width, 3), np.uint8) for _ in range(n)]
+        sp = (ctypes.c_void_p * n)(*[s.ctypes.data for s in scans])
+        sl = (ctypes.c_size_t * n)(*[s.size for s in scans])
+        op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+        self._chk(self.lib.kpeg_hip_decode_batch(self._h, n, ctypes.byref(frame), sp, sl, op))
+        return outs
+
+    def decode_batch_dev(self, frame, d_scans, scan_lens, d_rgbs):
+        """device pointers (ints); asynchronous, errors surface at sync()."""
+        n = len(d_scans)
+        sp = (ctypes.c_void_p * n)(*d_scans)
+        sl = (ctypes.c_size_t * n)(*scan_lens)
+        op = (ctypes.c_void_p * n)(*d_rgbs)
+        self._chk(self.lib.kpeg_hip_decode_batch_dev(self._h, n, ctypes.byref(frame), sp, sl, op))
 
     # -- device-resident entry points (raw device pointers, e.g. torch tensors' data_ptr())
     def idct_colour_dev(self, frame, d_coef, d_rgb):

@@ -52,6 +52,21 @@ struct kpeg_hip_ctx {
     bool ev_rec[EV_COUNT] = {};
     kpeg_hip_timings timings = {};
     bool status_pending = false;
+
+    // throughput mode (kpeg_hip_decode_batch*): independent images go round-robin to NLANES child contexts,
+    // each with its own stream and scratch, so that one image's latency-bound entropy kernels overlap
+    // another's IDCT and the launch gaps of small images overlap each other
+#ifndef KPEG_LANES
+#define KPEG_LANES 6
+#endif
+    static const int NLANES = KPEG_LANES;
+    kpeg_hip_ctx* lanes[NLANES] = {};
+    hipEvent_t lane_ev[NLANES + 1] = {};   // [NLANES] = fork point on the parent's stream
+    bool keep_status = false;              // lane: do not clear the status words (errors of earlier images must survive)
+    bool defer_status = false;             // lane: the status words are fetched once, when the batch joins
+    bool lanes_pending = false;            // parent: lanes hold deferred status
+    void* h_scan = nullptr;                // lane: pinned staging for host-buffer batches
+    size_t h_scan_cap = 0;
 };
 
 #define HIPCHK(ctx, expr)                                                                          \
@@ -142,6 +157,11 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (int l = 0; l < kpeg_hip_ctx::NLANES; ++l)
+        if (ctx->lanes[l]) kpeg_hip_destroy(ctx->lanes[l]);
+    for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
+        if (ctx->lane_ev[l]) (void)hipEventDestroy(ctx->lane_ev[l]);
+    if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     if (ctx->d_coef) (void)hipFree(ctx->d_coef);
     if (ctx->d_scan) (void)hipFree(ctx->d_scan);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
@@ -194,6 +214,23 @@ extern "C" int kpeg_hip_sync(kpeg_hip_ctx* ctx)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     int rc = KPEG_HIP_OK;
+    if (ctx->lanes_pending) {
+        // a batch: every lane's deferred status (errors are OR-ed over the lane's images)
+        ctx->lanes_pending = false;
+        uint32_t ex = 0;
+        for (int l = 0; l < kpeg_hip_ctx::NLANES; ++l) {
+            kpeg_hip_ctx* c = ctx->lanes[l];
+            if (!c) continue;
+            const int lrc = kpeg_hip_sync(c);
+            c->keep_status = false;
+            ex += c->timings.exact_pixels;
+            if (lrc && !rc) {
+                rc = lrc;
+                ctx->last_error = "batch: " + c->last_error;
+            }
+        }
+        ctx->timings.exact_pixels = ex;
+    }
     if (ctx->status_pending) {
         ctx->status_pending = false;
         uint32_t ex = 0;
@@ -295,6 +332,7 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
 
 static int finish_async(kpeg_hip_ctx* ctx)
 {
+    if (ctx->defer_status) return KPEG_HIP_OK;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, STATUS_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     ctx->status_pending = true;
     return KPEG_HIP_OK;
@@ -309,7 +347,7 @@ extern "C" int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, 
     begin_call(ctx);
     const uint32_t nblocks = (f->width / 8) * (f->height / 8) * 3;
     if ((rc = grow(ctx, &ctx->d_ebound, &ctx->ebound_cap, (size_t)nblocks * sizeof(float)))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    if (!ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     {
         // caller-supplied coefficients carry no error bounds: derive them (K2 does this on the decode path)
@@ -380,7 +418,7 @@ extern "C" int kpeg_hip_entropy_decode_dev(kpeg_hip_ctx* ctx, const kpeg_frame* 
     if (!d_scan || !scan_len || !d_coef) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     begin_call(ctx);
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    if (!ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     rc = run_entropy(ctx, f, d_scan, scan_len, (f->width / 8) * (f->height / 8), d_coef);
     if (rc) return rc;
@@ -407,7 +445,7 @@ extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f
     const size_t nmcu = (size_t)mw * mcu_rows;
     if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
     begin_call(ctx);
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    if (!ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     rc = run_entropy(ctx, f, d_scan, scan_len, (uint32_t)nmcu, (int16_t*)ctx->d_coef);
     if (rc) return rc;
@@ -440,20 +478,127 @@ extern "C" int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
     return kpeg_hip_sync(ctx);
 }
 
+static int ensure_lanes(kpeg_hip_ctx* ctx)
+{
+    for (int l = 0; l < kpeg_hip_ctx::NLANES; ++l) {
+        if (!ctx->lanes[l]) {
+            int rc = kpeg_hip_create(&ctx->lanes[l], ctx->device);
+            if (rc) {
+                ctx->last_error = "batch lane: kpeg_hip_create failed";
+                return rc;
+            }
+        }
+        ctx->lanes[l]->idct_mode = ctx->idct_mode;
+        ctx->lanes[l]->sync_passes = ctx->sync_passes;
+        ctx->lanes[l]->warm = ctx->warm;
+    }
+    for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
+        if (!ctx->lane_ev[l]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
+    return KPEG_HIP_OK;
+}
+
+// lanes start behind whatever is already queued on the parent's stream ...
+static int lanes_fork(kpeg_hip_ctx* ctx)
+{
+    HIPCHK(ctx, hipEventRecord(ctx->lane_ev[kpeg_hip_ctx::NLANES], ctx->stream));
+    for (int l = 0; l < kpeg_hip_ctx::NLANES; ++l) {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->lanes[l]->stream, ctx->lane_ev[kpeg_hip_ctx::NLANES], 0));
+        ctx->lanes[l]->keep_status = false;   // the lane's first image clears its status words, the later ones add to them
+        ctx->lanes[l]->defer_status = true;
+    }
+    return KPEG_HIP_OK;
+}
+
+// ... and the parent's stream continues behind all of them
+static int lanes_join(kpeg_hip_ctx* ctx)
+{
+    for (int l = 0; l < kpeg_hip_ctx::NLANES; ++l) {
+        ctx->lanes[l]->defer_status = false;
+        if (ctx->lanes[l]->keep_status) {   // the lane decoded something
+            int rc = finish_async(ctx->lanes[l]);
+            if (rc) return rc;
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->lane_ev[l], ctx->lanes[l]->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
+    }
+    ctx->lanes_pending = true;
+    return KPEG_HIP_OK;
+}
+
+extern "C" int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f, const uint8_t* const* d_scans,
+                                         const size_t* scan_lens, uint8_t* const* d_rgbs)
+{
+    int rc = check_frame(ctx, f);
+    if (rc) return rc;
+    if (count <= 0 || !d_scans || !scan_lens || !d_rgbs) return KPEG_HIP_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_lanes(ctx))) return rc;
+    if ((rc = lanes_fork(ctx))) return rc;
+    for (int i = 0; i < count; ++i) {
+        kpeg_hip_ctx* c = ctx->lanes[i % kpeg_hip_ctx::NLANES];
+        rc = kpeg_hip_decode_scan_dev(c, f, d_scans[i], scan_lens[i], d_rgbs[i]);
+        c->keep_status = true;
+        if (rc) {
+            ctx->last_error = "batch image " + std::to_string(i) + ": " + c->last_error;
+            (void)lanes_join(ctx);
+            return rc;
+        }
+    }
+    return lanes_join(ctx);
+}
+
 extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f, const uint8_t* const* scans,
                                      const size_t* scan_lens, uint8_t* const* rgbs)
 {
     int rc = check_frame(ctx, f);
     if (rc) return rc;
     if (count <= 0 || !scans || !scan_lens || !rgbs) return KPEG_HIP_E_ARG;
-    // Throughput mode: images are independent; they are decoded back to back on the
-    // context's stream, uploads/downloads of neighbours overlapping through pinned staging
-    // is left to the device-resident API (bench.py drives that one).
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = ensure_lanes(ctx))) return rc;
+    if ((rc = lanes_fork(ctx))) return rc;
+    const size_t rbytes = (size_t)f->width * f->height * 3;
+    const int NL = kpeg_hip_ctx::NLANES;
+    // Software pipeline over the lanes: image i is uploaded (through the lane's pinned staging, so the copy
+    // is truly asynchronous) and its kernels are enqueued; the download of image i - (NL - 1), whose kernels
+    // have had that long to finish, is issued afterwards.  A download into pageable memory blocks the
+    // host, which is exactly when the other lanes' kernels run.
+    auto download = [&](int j) -> int {
+        kpeg_hip_ctx* c = ctx->lanes[j % NL];
+        HIPCHK(ctx, hipMemcpyAsync(rgbs[j], c->d_rgb, rbytes, hipMemcpyDeviceToHost, c->stream));
+        return KPEG_HIP_OK;
+    };
     for (int i = 0; i < count; ++i) {
-        rc = kpeg_hip_decode_scan(ctx, f, scans[i], scan_lens[i], rgbs[i]);
-        if (rc) return rc;
+        kpeg_hip_ctx* c = ctx->lanes[i % NL];
+        if (!scans[i] || !scan_lens[i] || !rgbs[i]) return KPEG_HIP_E_ARG;
+        if ((rc = grow(c, &c->d_scan, &c->scan_cap, scan_lens[i] + 64))) return rc;
+        if ((rc = grow(c, &c->d_rgb, &c->rgb_cap, rbytes))) return rc;
+        if (scan_lens[i] > c->h_scan_cap) {
+            HIPCHK(ctx, hipStreamSynchronize(c->stream));
+            if (c->h_scan) (void)hipHostFree(c->h_scan);
+            c->h_scan = nullptr;
+            c->h_scan_cap = 0;
+            const size_t want = scan_lens[i] + scan_lens[i] / 4 + 4096;
+            HIPCHK(ctx, hipHostMalloc(&c->h_scan, want, hipHostMallocDefault));
+            c->h_scan_cap = want;
+        }
+        // the lane's previous image (i - NL) has been downloaded: its stream is past the staging buffer's last use
+        if (i >= NL) HIPCHK(ctx, hipStreamSynchronize(c->stream));
+        std::memcpy(c->h_scan, scans[i], scan_lens[i]);
+        HIPCHK(ctx, hipMemcpyAsync(c->d_scan, c->h_scan, scan_lens[i], hipMemcpyHostToDevice, c->stream));
+        rc = kpeg_hip_decode_scan_dev(c, f, (const uint8_t*)c->d_scan, scan_lens[i], (uint8_t*)c->d_rgb);
+        c->keep_status = true;
+        if (rc) {
+            ctx->last_error = "batch image " + std::to_string(i) + ": " + c->last_error;
+            (void)lanes_join(ctx);
+            (void)kpeg_hip_sync(ctx);
+            return rc;
+        }
+        if (i >= NL - 1 && (rc = download(i - (NL - 1)))) return rc;
     }
-    return KPEG_HIP_OK;
+    for (int j = count > NL - 1 ? count - (NL - 1) : 0; j < count; ++j)
+        if ((rc = download(j))) return rc;
+    if ((rc = lanes_join(ctx))) return rc;
+    return kpeg_hip_sync(ctx);
 }
 
 // test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default)

@@ -225,23 +225,50 @@ def test_full_size_8k_properties(ctx):
 
 
 def test_decode_batch(ctx):
-    """kpeg_hip_decode_batch: independent images of one geometry and one set of tables."""
-    import ctypes
+    """kpeg_hip_decode_batch: independent images of one geometry and one set of tables, pipelined over the
+    context's lanes (more images than lanes, scans of different lengths)."""
     import libkpeg_amd as K
-    w, h, n = 128, 64, 5
-    datas = [T.synth_jpeg(w, h, seed=40 + i) for i in range(n)]
+    w, h, n = 256, 128, 11
+    datas = [T.synth_jpeg(w, h, seed=40 + i, sigma=2.0 + 3 * (i % 4)) for i in range(n)]
     parsed = [K.host_parse(d) for d in datas]
-    frame = parsed[0][1]
-    scans = [np.ascontiguousarray(p[2]) for p in parsed]
-    outs = [np.empty((h, w, 3), np.uint8) for _ in range(n)]
-    sp = (ctypes.c_void_p * n)(*[s.ctypes.data for s in scans])
-    sl = (ctypes.c_size_t * n)(*[s.size for s in scans])
-    op = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
-    rc = ctx.lib.kpeg_hip_decode_batch(ctx._h, n, ctypes.byref(frame), sp, sl, op)
-    assert rc == 0
+    outs = ctx.decode_batch(parsed[0][1], [p[2] for p in parsed])
     for d, o in zip(datas, outs):
         st, want = T.oracle_decode(d)
         assert np.array_equal(o, want)
+    # one of them again through the ordinary entry point: the lanes left the parent context intact
+    assert np.array_equal(ctx.decode_scan(parsed[3][1], parsed[3][2]), outs[3])
+
+
+def test_decode_batch_dev_and_error(ctx):
+    """Device-resident batch on the caller's stream; a truncated scan in the middle fails the batch at sync()
+    while the other images are still decoded."""
+    import torch
+    import libkpeg_amd as K
+    w, h, n = 128, 128, 9
+    datas = [T.synth_jpeg(w, h, seed=70 + i) for i in range(n)]
+    parsed = [K.host_parse(d) for d in datas]
+    frame = parsed[0][1]
+    d_scans = [torch.from_numpy(np.ascontiguousarray(p[2])).cuda() for p in parsed]
+    d_rgbs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans], [t.numel() for t in d_scans], [t.data_ptr() for t in d_rgbs])
+    ctx.sync()
+    for d, o in zip(datas, d_rgbs):
+        st, want = T.oracle_decode(d)
+        assert np.array_equal(o.cpu().numpy(), want)
+    lens = [t.numel() for t in d_scans]
+    lens[4] //= 2   # truncated: the blocks of the second half never arrive
+    for t in d_rgbs:
+        t.zero_()
+    torch.cuda.synchronize()
+    ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans], lens, [t.data_ptr() for t in d_rgbs])
+    with pytest.raises(RuntimeError):
+        ctx.sync()
+    st, want = T.oracle_decode(datas[5])
+    assert np.array_equal(d_rgbs[5].cpu().numpy(), want)
+    # and the context is usable afterwards
+    ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans[:2]], [t.numel() for t in d_scans[:2]], [t.data_ptr() for t in d_rgbs[:2]])
+    ctx.sync()
 
 
 def test_bench_multi_gpu_path_rehearsal():
