@@ -73,7 +73,40 @@ struct IdctParams {
     uint32_t ntiles;      // tiles_w * mcu_rows
     uint32_t* stats;      // [256] counters: [blockIdx & 255] += pixels sent to the exact path (may be null)
     uint32_t skip_exact;  // timing experiments only: count unsafe pixels but do not re-evaluate them
+    uint32_t* status;     // the call's status words (device): stats == status + 16, [3] = wavefronts of this launch that are done
+    uint32_t* h_status;   // host-pinned mirror (device address) or null: the launch's last wavefront copies the device words to it and clears them
+    uint32_t keep_status; // batch lanes: leave the device words standing (error flags and counters accumulate over the lane's images)
 };
+
+constexpr uint32_t KPEG_STATUS_WORDS = 16 + 256 + 64;   // [1] error flags, [2] K1 passes, [3] + [272..335] end-of-call tickets, [16..271] counters
+
+// End of a call's last kernel, every wavefront: the last one to get here hands the status words to the host
+// mirror (plain posted stores: no read over PCIe) and leaves the device words zero for the next call -- no
+// memset and no copy operation around a decode.  keep: the words stay (a batch lane accumulates error flags
+// and counters over its images; the mirror then always holds the sums so far).
+// No fences (a release fence writes back the XCD's whole L2: 1280 of them tripled K4's time): every status update
+// is a device-scope atomic performed at L2; `dep` is the value returned by this wavefront's own last update, so
+// that update has been performed before the ticket is taken, and the last wavefront reads the words at L2.
+__device__ __forceinline__ void status_epilogue(uint32_t* status, uint32_t* h_status, uint32_t nwaves, uint32_t keep, uint32_t dep)
+{
+    if (!h_status) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t last = 0;
+    if (lane == 0) {
+        // two levels (1280 tickets on one word would queue up for ~30 us at the kernel's tail): 64 slot words,
+        // the wavefront that completes its slot takes one of 64 tickets on the top word
+        const uint32_t slot = blockIdx.x & 63, in_slot = (nwaves - slot + 63) >> 6;
+        if (atomicAdd(&status[272 + slot], 1u + (dep & 0u)) == in_slot - 1)
+            last = atomicAdd(&status[3], 1u) == min(nwaves, 64u) - 1 ? 1u : 0u;
+    }
+    if (!__shfl((int)last, 0)) return;
+    for (uint32_t w = lane; w < KPEG_STATUS_WORDS; w += 64) {
+        const bool ticket = w == 3 || w >= 272;
+        const uint32_t v = ticket ? 0u : __hip_atomic_load(&status[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h_status[w] = v;
+        if (!keep || ticket) status[w] = 0;
+    }
+}
 
 // ---- reference-order arithmetic ---------------------------------
 // Compiled with -ffp-contract=off: each operation below is one IEEE operation.
@@ -775,7 +808,9 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     }
     if (prev_tile != 0xFFFFFFFFu) write_back(prev_tile);
     // one fire-and-forget add per wavefront, spread over 256 words (a single hot word serialises in L2)
-    if (tid == 0 && nq_total && p.stats) atomicAdd(&p.stats[blockIdx.x & 255], nq_total);
+    uint32_t dep = 0;
+    if (tid == 0 && nq_total && p.stats) dep = atomicAdd(&p.stats[blockIdx.x & 255], nq_total);
+    status_epilogue(p.status, p.h_status, gridDim.x, p.keep_status, dep);
 }
 
 }  // namespace kpeg_dev

@@ -19,7 +19,7 @@
 
 using namespace kpeg_dev;
 
-static const size_t STATUS_WORDS = 16 + 256, STATUS_BYTES = STATUS_WORDS * 4;
+static const size_t STATUS_WORDS = KPEG_STATUS_WORDS, STATUS_BYTES = STATUS_WORDS * 4;
 
 // ---------------------------------------------------------------------------------------------
 struct kpeg_hip_ctx {
@@ -45,13 +45,16 @@ struct kpeg_hip_ctx {
     EntropyScratch ent;        // K0..K3 work buffers
     // [0] unused, [1] entropy error flag, [2] sync passes, [16..271] K4 exact-pixel counters
     uint32_t* d_status = nullptr;
-    uint32_t* h_status = nullptr;  // pinned mirror
+    uint32_t* h_status = nullptr;  // pinned mirror: the last kernel of every call adds the device words to it, kpeg_hip_sync reads and clears it
+    uint32_t* h_status_dev = nullptr;  // its device address
+    bool status_clean = false;     // the device words are zero (the previous call's last kernel cleared them)
 
     enum { EV_BEGIN, EV_UNSTUFF, EV_SYNC, EV_SCAN, EV_WRITE, EV_DC, EV_IDCT, EV_COUNT };
     hipEvent_t ev[EV_COUNT] = {};
     bool ev_rec[EV_COUNT] = {};
     kpeg_hip_timings timings = {};
     bool status_pending = false;
+    uint32_t status_seen[KPEG_STATUS_WORDS] = {};   // what the last kpeg_hip_sync read (test hook)
 
     // throughput mode (kpeg_hip_decode_batch*): independent images go round-robin to NLANES child contexts,
     // each with its own stream and scratch, so that one image's latency-bound entropy kernels overlap
@@ -62,9 +65,8 @@ struct kpeg_hip_ctx {
     static const int NLANES = KPEG_LANES;
     kpeg_hip_ctx* lanes[NLANES] = {};
     hipEvent_t lane_ev[NLANES + 1] = {};   // [NLANES] = fork point on the parent's stream
-    bool keep_status = false;              // lane: do not clear the status words (errors of earlier images must survive)
-    bool defer_status = false;             // lane: the status words are fetched once, when the batch joins
     bool lanes_pending = false;            // parent: lanes hold deferred status
+    bool keep_status = false;              // lane, during a batch: the device status words accumulate over the lane's images
     void* h_scan = nullptr;                // lane: pinned staging for host-buffer batches
     size_t h_scan_cap = 0;
 };
@@ -148,6 +150,9 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
     if ((e = hipMalloc((void**)&ctx->d_status, STATUS_BYTES)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&ctx->h_status, STATUS_BYTES, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
     std::memset(ctx->h_status, 0, STATUS_BYTES);
+    if ((e = hipHostGetDevicePointer((void**)&ctx->h_status_dev, ctx->h_status, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
+    if ((e = hipMemset(ctx->d_status, 0, STATUS_BYTES)) != hipSuccess) return fail("hipMemset", e);
+    ctx->status_clean = true;
     *out = ctx;
     return KPEG_HIP_OK;
 }
@@ -223,6 +228,7 @@ extern "C" int kpeg_hip_sync(kpeg_hip_ctx* ctx)
             if (!c) continue;
             const int lrc = kpeg_hip_sync(c);
             c->keep_status = false;
+            c->status_clean = false;   // the sums are still standing on the device
             ex += c->timings.exact_pixels;
             if (lrc && !rc) {
                 rc = lrc;
@@ -241,6 +247,8 @@ extern "C" int kpeg_hip_sync(kpeg_hip_ctx* ctx)
             ctx->last_error = "entropy decode flagged the stream as invalid (code " + std::to_string(ctx->h_status[1]) + ")";
             rc = KPEG_HIP_E_STREAM;
         }
+        std::memcpy(ctx->status_seen, ctx->h_status, STATUS_BYTES);
+        std::memset(ctx->h_status, 0, STATUS_BYTES);   // the stream is idle: nothing is adding to it
     }
     if (ctx->profiling) {
         auto span = [&](int a, int b) -> float {
@@ -302,6 +310,9 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     p.mcu_rows = mcu_rows;
     p.pitch = f->width * 3;
     p.stats = ctx->d_status + 16;
+    p.status = ctx->d_status;
+    p.h_status = ctx->idct_mode == 1 ? nullptr : ctx->h_status_dev;   // the per-MCU exact kernel has no epilogue
+    p.keep_status = ctx->keep_status ? 1u : 0u;
     p.skip_exact = ctx->idct_mode == 2;
     if (ctx->idct_mode == 1) {
         p.tiles_w = 0;
@@ -330,10 +341,17 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     return KPEG_HIP_OK;
 }
 
-static int finish_async(kpeg_hip_ctx* ctx)
+__global__ void k_status_flush(uint32_t* status, uint32_t* h_status, uint32_t keep) { status_epilogue(status, h_status, 1, keep, 0); }
+
+// End of an enqueued call: the status words reach the host mirror and the device words are zero again --
+// done by K4's last wavefront when K4 was the call's last kernel, else by a one-wavefront kernel.
+static int finish_async(kpeg_hip_ctx* ctx, bool k4_did_it)
 {
-    if (ctx->defer_status) return KPEG_HIP_OK;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, STATUS_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    if (!k4_did_it) {
+        hipLaunchKernelGGL(k_status_flush, dim3(1), dim3(64), 0, ctx->stream, ctx->d_status, ctx->h_status_dev, ctx->keep_status ? 1u : 0u);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    ctx->status_clean = !ctx->keep_status;
     ctx->status_pending = true;
     return KPEG_HIP_OK;
 }
@@ -347,7 +365,8 @@ extern "C" int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, 
     begin_call(ctx);
     const uint32_t nblocks = (f->width / 8) * (f->height / 8) * 3;
     if ((rc = grow(ctx, &ctx->d_ebound, &ctx->ebound_cap, (size_t)nblocks * sizeof(float)))) return rc;
-    if (!ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    if (!ctx->status_clean && !ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    ctx->status_clean = false;
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     {
         // caller-supplied coefficients carry no error bounds: derive them (K2 does this on the decode path)
@@ -360,7 +379,7 @@ extern "C" int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, 
     rc = launch_idct(ctx, f, d_coef, d_rgb, f->height / 8);
     if (rc) return rc;
     mark(ctx, kpeg_hip_ctx::EV_IDCT);
-    return finish_async(ctx);
+    return finish_async(ctx, ctx->idct_mode != 1);
 }
 
 extern "C" int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* coef, uint8_t* rgb)
@@ -418,11 +437,12 @@ extern "C" int kpeg_hip_entropy_decode_dev(kpeg_hip_ctx* ctx, const kpeg_frame* 
     if (!d_scan || !scan_len || !d_coef) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     begin_call(ctx);
-    if (!ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    if (!ctx->status_clean && !ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    ctx->status_clean = false;
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     rc = run_entropy(ctx, f, d_scan, scan_len, (f->width / 8) * (f->height / 8), d_coef);
     if (rc) return rc;
-    return finish_async(ctx);
+    return finish_async(ctx, false);
 }
 
 extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len,
@@ -445,14 +465,15 @@ extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f
     const size_t nmcu = (size_t)mw * mcu_rows;
     if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
     begin_call(ctx);
-    if (!ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    if (!ctx->status_clean && !ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    ctx->status_clean = false;
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
     rc = run_entropy(ctx, f, d_scan, scan_len, (uint32_t)nmcu, (int16_t*)ctx->d_coef);
     if (rc) return rc;
     rc = launch_idct(ctx, f, (const int16_t*)ctx->d_coef, d_rgb, mcu_rows);
     if (rc) return rc;
     mark(ctx, kpeg_hip_ctx::EV_IDCT);
-    return finish_async(ctx);
+    return finish_async(ctx, ctx->idct_mode != 1);
 }
 
 extern "C" int kpeg_hip_decode_scan_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len,
@@ -503,8 +524,10 @@ static int lanes_fork(kpeg_hip_ctx* ctx)
     HIPCHK(ctx, hipEventRecord(ctx->lane_ev[kpeg_hip_ctx::NLANES], ctx->stream));
     for (int l = 0; l < kpeg_hip_ctx::NLANES; ++l) {
         HIPCHK(ctx, hipStreamWaitEvent(ctx->lanes[l]->stream, ctx->lane_ev[kpeg_hip_ctx::NLANES], 0));
-        ctx->lanes[l]->keep_status = false;   // the lane's first image clears its status words, the later ones add to them
-        ctx->lanes[l]->defer_status = true;
+        kpeg_hip_ctx* c = ctx->lanes[l];
+        if (!c->status_clean) HIPCHK(ctx, hipMemsetAsync(c->d_status, 0, STATUS_BYTES, c->stream));
+        c->status_clean = true;
+        c->keep_status = true;   // error flags and counters of the lane's images add up on the device
     }
     return KPEG_HIP_OK;
 }
@@ -513,11 +536,6 @@ static int lanes_fork(kpeg_hip_ctx* ctx)
 static int lanes_join(kpeg_hip_ctx* ctx)
 {
     for (int l = 0; l < kpeg_hip_ctx::NLANES; ++l) {
-        ctx->lanes[l]->defer_status = false;
-        if (ctx->lanes[l]->keep_status) {   // the lane decoded something
-            int rc = finish_async(ctx->lanes[l]);
-            if (rc) return rc;
-        }
         HIPCHK(ctx, hipEventRecord(ctx->lane_ev[l], ctx->lanes[l]->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[l], 0));
     }
@@ -537,7 +555,6 @@ extern "C" int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpe
     for (int i = 0; i < count; ++i) {
         kpeg_hip_ctx* c = ctx->lanes[i % kpeg_hip_ctx::NLANES];
         rc = kpeg_hip_decode_scan_dev(c, f, d_scans[i], scan_lens[i], d_rgbs[i]);
-        c->keep_status = true;
         if (rc) {
             ctx->last_error = "batch image " + std::to_string(i) + ": " + c->last_error;
             (void)lanes_join(ctx);
@@ -586,7 +603,6 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
         std::memcpy(c->h_scan, scans[i], scan_lens[i]);
         HIPCHK(ctx, hipMemcpyAsync(c->d_scan, c->h_scan, scan_lens[i], hipMemcpyHostToDevice, c->stream));
         rc = kpeg_hip_decode_scan_dev(c, f, (const uint8_t*)c->d_scan, scan_lens[i], (uint8_t*)c->d_rgb);
-        c->keep_status = true;
         if (rc) {
             ctx->last_error = "batch image " + std::to_string(i) + ": " + c->last_error;
             (void)lanes_join(ctx);
@@ -615,6 +631,6 @@ extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
 extern "C" int kpeg_hip_debug_words(kpeg_hip_ctx* ctx, uint32_t* out, int n)
 {
     if (!ctx || !out) return KPEG_HIP_E_ARG;
-    for (int i = 0; i < n && i < (int)STATUS_WORDS; ++i) out[i] = ctx->h_status[i];
+    for (int i = 0; i < n && i < (int)STATUS_WORDS; ++i) out[i] = ctx->status_seen[i];
     return KPEG_HIP_OK;
 }
