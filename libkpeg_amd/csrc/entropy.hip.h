@@ -228,80 +228,95 @@ constexpr int US_BYTES_PER_THREAD = 16;
 constexpr int US_THREADS = 256;
 constexpr int US_BLOCK_BYTES = US_BYTES_PER_THREAD * US_THREADS;
 
-__device__ __forceinline__ void us_flags(const uint8_t* b, uint32_t n, uint32_t j0, bool rst, uint32_t& keepmask,
-                                         uint32_t& markmask)
+// keep / marker flags of one thread's 16 bytes, held in w[0..3] (little-endian), prev = the byte before them,
+// next = the byte after them (0x100 = none); nvalid = how many of the 16 exist
+__device__ __forceinline__ void us_flags(const uint32_t w[4], uint32_t prev, uint32_t next, uint32_t nvalid, bool last_is_final, bool rst,
+                                         uint32_t& keepmask, uint32_t& markmask)
 {
     keepmask = 0;
     markmask = 0;
-    uint32_t prev = j0 > 0 && j0 - 1 < n ? b[j0 - 1] : 0x100;
+#pragma unroll
     for (int k = 0; k < US_BYTES_PER_THREAD; ++k) {
-        uint32_t j = j0 + k;
-        if (j >= n) break;
-        uint32_t cur = b[j];
+        const uint32_t cur = (w[k >> 2] >> ((k & 3) * 8)) & 0xFF;
+        const uint32_t nxt = k + 1 < US_BYTES_PER_THREAD ? (w[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 0xFF : next;
+        const bool exists = (uint32_t)k < nvalid;
+        const bool has_next = (uint32_t)(k + 1) < nvalid || (nvalid == US_BYTES_PER_THREAD && !last_is_final);
         bool keep = true;
         if (rst) {
-            uint32_t nxt = j + 1 < n ? b[j + 1] : 0x100;
+            const uint32_t nx = has_next ? nxt : 0x100u;
             if (cur == 0x00 && prev == 0xFF) keep = false;
-            if (cur == 0xFF && nxt >= 0xD0 && nxt <= 0xD7) {
+            if (cur == 0xFF && nx >= 0xD0 && nx <= 0xD7) {
                 keep = false;
-                markmask |= 1u << k;  // a marker starts here
+                if (exists) markmask |= 1u << k;  // a marker starts here
             }
             if (prev == 0xFF && cur >= 0xD0 && cur <= 0xD7) keep = false;
         } else {
-            if (cur == 0x00 && prev == 0xFF && j + 1 < n) keep = false;  // never the last byte
+            if (cur == 0x00 && prev == 0xFF && has_next) keep = false;  // never the last byte
         }
-        if (keep) keepmask |= 1u << k;
+        if (keep && exists) keepmask |= 1u << k;
         prev = cur;
     }
 }
 
-// One launch: every workgroup flags its 4 KiB, scans its keep/marker counts, gets its base from its
-// predecessors by decoupled look-back (aggregate / inclusive prefix published in one 64-bit word:
-// kept bytes [27:0], markers [54:28], state [63:62]; workgroups are dispatched in index order), then
-// scatters.  The last workgroup knows the totals; without restart markers it also does k_seg_setup's
-// job (one segment), which saves that launch.  part[] must be zero on entry: K1's last launch clears
-// it for the next call.
+// One launch: every workgroup flags its 4 KiB (one 16-byte load per thread), scans its keep/marker counts,
+// gets its base from its predecessors by decoupled look-back (aggregate / inclusive prefix published in one
+// 64-bit word: kept bytes [27:0], markers [54:28], state [63:62]; workgroups are dispatched in index order),
+// compacts its kept bytes in LDS in their final word order and writes them out as whole words.  The last
+// workgroup knows the totals; without restart markers it also does k_seg_setup's job (one segment), which
+// saves that launch.  part[] must be zero on entry: K1's last launch clears it for the next call.
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PFX = 2ull << 62;
 __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
                                                         uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
                                                         uint32_t nsub_cap, uint32_t* status)
 {
-    __shared__ uint32_t s_k[US_THREADS], s_m[US_THREADS];
+    __shared__ uint32_t s_wave[US_THREADS / 64];
     __shared__ uint32_t s_base[2];
-    const uint32_t g = blockIdx.x;
-    uint32_t j0 = (g * US_THREADS + threadIdx.x) * US_BYTES_PER_THREAD;
-    uint32_t km, mm;
-    us_flags(b, n, j0, rst != 0, km, mm);
-    s_k[threadIdx.x] = __popc(km);
-    s_m[threadIdx.x] = __popc(mm);
-    __syncthreads();
-    // simple Hillis-Steele inclusive scan over 256 entries
-    for (int o = 1; o < US_THREADS; o <<= 1) {
-        uint32_t a = 0, c = 0;
-        if ((int)threadIdx.x >= o) {
-            a = s_k[threadIdx.x - o];
-            c = s_m[threadIdx.x - o];
-        }
-        __syncthreads();
-        s_k[threadIdx.x] += a;
-        s_m[threadIdx.x] += c;
-        __syncthreads();
+    __shared__ uint32_t s_out[US_BLOCK_BYTES / 4 + 2];
+    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t j0 = (g * US_THREADS + t) * US_BYTES_PER_THREAD;
+    const uint32_t nvalid = j0 >= n ? 0u : min((uint32_t)US_BYTES_PER_THREAD, n - j0);
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (nvalid == US_BYTES_PER_THREAD && (reinterpret_cast<uintptr_t>(b) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(b + j0);
+        w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    } else {
+        for (uint32_t k = 0; k < nvalid; ++k) w[k >> 2] |= (uint32_t)b[j0 + k] << ((k & 3) * 8);
     }
-    if (threadIdx.x < 64) {
+    // the bytes around: from the neighbouring lanes, from memory at the wavefront's edges
+    uint32_t prev = (uint32_t)__shfl_up((int)(w[3] >> 24), 1), next = (uint32_t)__shfl_down((int)(w[0] & 0xFF), 1);
+    if (lane == 0) prev = j0 > 0 && j0 - 1 < n ? b[j0 - 1] : 0x100u;
+    if (lane == 63) next = j0 + US_BYTES_PER_THREAD < n ? b[j0 + US_BYTES_PER_THREAD] : 0x100u;
+    uint32_t km, mm;
+    us_flags(w, prev, next, nvalid, j0 + US_BYTES_PER_THREAD >= n, rst != 0, km, mm);
+    // inclusive scan of (kept, markers) packed as kept | markers << 16: inside the wavefront, then over the four wavefronts
+    const uint32_t own = __popc(km) | (__popc(mm) << 16);
+    uint32_t v = own;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)v, o);
+        if ((int)lane >= o) v += x;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+    for (uint32_t q = 0; q < US_THREADS / 64; ++q) {
+        if (q < wave) woff += s_wave[q];
+        total += s_wave[q];
+    }
+    const uint32_t tk = total & 0xFFFF, tm = total >> 16;
+    if (t < 64) {
         // wavefront 0 looks back 64 predecessors at a time: the nearest inclusive prefix ends the walk
-        const uint32_t lane = threadIdx.x;
-        const unsigned long long mine = (unsigned long long)s_k[US_THREADS - 1] | ((unsigned long long)s_m[US_THREADS - 1] << 28);
+        const unsigned long long mine = (unsigned long long)tk | ((unsigned long long)tm << 28);
         if (lane == 0 && g > 0) __hip_atomic_store(&part[g], mine | LB_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t acc_k = 0, acc_m = 0;
         for (int base = (int)g - 1; base >= 0; base -= 64) {
             const int j = base - (int)lane;
-            unsigned long long v = LB_PFX;   // before the first workgroup: prefix 0
+            unsigned long long pv = LB_PFX;   // before the first workgroup: prefix 0
             if (j >= 0)
-                while (((v = __hip_atomic_load(&part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
-            const unsigned long long pfx = __ballot((v >> 62) == 2);
+                while (((pv = __hip_atomic_load(&part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+            const unsigned long long pfx = __ballot((pv >> 62) == 2);
             const uint32_t first = pfx ? (uint32_t)__builtin_ctzll(pfx) : 63u;
-            uint32_t k = lane <= first ? (uint32_t)(v & 0xFFFFFFFu) : 0u;
-            uint32_t m = lane <= first ? (uint32_t)((v >> 28) & 0x7FFFFFFu) : 0u;
+            uint32_t k = lane <= first ? (uint32_t)(pv & 0xFFFFFFFu) : 0u;
+            uint32_t m = lane <= first ? (uint32_t)((pv >> 28) & 0x7FFFFFFu) : 0u;
             for (int o = 32; o > 0; o >>= 1) {
                 k += __shfl_down(k, o);
                 m += __shfl_down(m, o);
@@ -318,31 +333,51 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         }
     }
     __syncthreads();
-    uint32_t pos = s_base[0] + s_k[threadIdx.x] - __popc(km);
-    uint32_t mk = s_base[1] + s_m[threadIdx.x] - __popc(mm);
-    for (int k = 0; k < US_BYTES_PER_THREAD; ++k) {
-        uint32_t j = j0 + k;
-        if (j >= n) break;
-        if (mm & (1u << k)) {
-            mk++;
-            if (mk < seg_cap) seg_off[mk] = pos;  // segment mk starts at the next kept byte
-        }
-        if (km & (1u << k)) {
-            u[pos ^ 3] = b[j];  // big-endian words for little-endian 32-bit loads
-            pos++;
+    const uint32_t base_k = s_base[0], abase = base_k & ~3u;
+    {
+        const uint32_t excl = woff + v - own;
+        uint32_t pos = base_k + (excl & 0xFFFF);
+        uint32_t mk = s_base[1] + (excl >> 16);
+        uint8_t* so = reinterpret_cast<uint8_t*>(s_out);
+#pragma unroll
+        for (int k = 0; k < US_BYTES_PER_THREAD; ++k) {
+            if (mm & (1u << k)) {
+                mk++;
+                if (mk < seg_cap) seg_off[mk] = pos;  // segment mk starts at the next kept byte
+            }
+            if (km & (1u << k)) {
+                so[(pos - abase) ^ 3] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));  // big-endian words for little-endian 32-bit loads
+                pos++;
+            }
         }
     }
-    if (g == 0 && threadIdx.x == 0) seg_off[0] = 0;
+    __syncthreads();
+    {
+        // this workgroup's bytes [base_k, base_k + tk): whole words as words, the shared edge words byte by byte
+        const uint32_t end_k = base_k + tk;
+        const uint32_t nwords = tk ? ((end_k + 3) >> 2) - (abase >> 2) : 0u;
+        uint32_t* uw = reinterpret_cast<uint32_t*>(u) + (abase >> 2);
+        const uint8_t* so = reinterpret_cast<const uint8_t*>(s_out);
+        for (uint32_t wi = t; wi < nwords; wi += US_THREADS) {
+            const uint32_t p0 = abase + 4 * wi;
+            if (p0 >= base_k && p0 + 4 <= end_k) {
+                uw[wi] = s_out[wi];
+            } else {
+                for (uint32_t p = max(p0, base_k); p < min(p0 + 4, end_k); ++p) u[p ^ 3] = so[(p - abase) ^ 3];
+            }
+        }
+    }
+    if (g == 0 && t == 0) seg_off[0] = 0;
     if (g == gridDim.x - 1) {
-        const uint32_t n_u = s_base[0] + s_k[US_THREADS - 1], nseg = s_base[1] + s_m[US_THREADS - 1] + 1;
-        if (threadIdx.x == 0) {
+        const uint32_t n_u = base_k + tk, nseg = s_base[1] + tm + 1;
+        if (t == 0) {
             meta->n_u = n_u;
             meta->nseg = nseg;
         }
         if (!rst) {
             // one segment: what k_seg_setup does.  Bytes past the end read as zero (the readers look ahead).
-            if (threadIdx.x < 16) u[(n_u + threadIdx.x) ^ 3] = 0;
-            if (threadIdx.x == 0) {
+            if (t < 16) u[(n_u + t) ^ 3] = 0;
+            if (t == 0) {
                 uint32_t nsub = (n_u * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
                 if (nsub == 0) nsub = 1;
                 seg_off[1] = n_u;

@@ -224,6 +224,22 @@ def test_full_size_8k_properties(ctx):
     assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
 
 
+@pytest.mark.parametrize("offset", [1, 7])
+def test_unaligned_scan_pointer(ctx, offset):
+    """K0 loads 16 bytes per thread when the scan pointer allows it and falls back to bytes when not."""
+    import torch
+    data = T.synth_jpeg(512, 256, seed=91, restart_interval=0)
+    st, want = T.oracle_decode(data)
+    p = T.oracle_parse(data)
+    buf = torch.zeros(len(p.scan) + 64, dtype=torch.uint8, device="cuda")
+    buf[offset:offset + len(p.scan)] = torch.frombuffer(bytearray(p.scan), dtype=torch.uint8).cuda()
+    d_rgb = torch.empty((256, 512, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.decode_scan_dev(T.make_frame(p), buf.data_ptr() + offset, len(p.scan), d_rgb.data_ptr())
+    ctx.sync()
+    assert np.array_equal(d_rgb.cpu().numpy(), want)
+
+
 def test_decode_batch(ctx):
     """kpeg_hip_decode_batch: independent images of one geometry and one set of tables, pipelined over the
     context's lanes (more images than lanes, scans of different lengths)."""
