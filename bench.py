@@ -162,6 +162,9 @@ def main():
                     help="N>1 dry run on a one-GPU box: gloo backend, every rank on cuda:0 (the driver's runs use RCCL, one GPU per rank)")
     ap.add_argument("--idct-mode", type=int, default=0, help="kpeg_hip_set_idct_mode (2 = timing experiment, wrong pixels)")
     ap.add_argument("--idct-only", action="store_true", help="time K4 alone on resident coefficients (BASELINE config 2 style)")
+    ap.add_argument("--side-figures", action="store_true",
+                    help="also report SURVEY 8(d)'s side figures: measured device-copy ceiling and the dense q95 noise stress input "
+                         "(off by default so that a rocprofv3 summary of the default command holds the headline workload only)")
     ap.add_argument("--batch", type=int, default=0,
                     help="BASELINE config 4 instead of the headline: N synthetic 1920x1080 images (seeds 1234..), device-resident, "
                          "kpeg_hip_decode_batch_dev (six lanes) beside the one-stream loop; one step = the whole batch")
@@ -270,7 +273,7 @@ def main():
 
     # ---- SURVEY 8(d) side figures (single GPU, default workload): device-copy ceiling and the dense stress input
     copy_gbs = stress = None
-    if world == 1 and not args.idct_only and (W, H) == (W8K, H8K):
+    if args.side_figures and world == 1 and not args.idct_only and (W, H) == (W8K, H8K):
         a = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
         b = torch.empty_like(a)
         for _ in range(3):
