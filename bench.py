@@ -125,7 +125,7 @@ def bench_batch(args, torch, K):
             ctx.decode_scan_dev(frames, sp[i], sl[i], op[i])
 
     res = {}
-    for name, fn in (("lanes", lanes), ("one_stream", one_stream)):
+    for name, fn in (("lanes", lanes), ("one_stream", one_stream)):   # "lanes": historical name of the batch entry point's leg
         for _ in range(args.warmup):
             fn()
         ctx.sync()
@@ -143,7 +143,7 @@ def bench_batch(args, torch, K):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["lanes"] * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "batch of %d synthetic 1920x1080 4:4:4 baseline JPEGs q%d (%d distinct, seeds %d..), resident in HBM, "
-                               "kpeg_hip_decode_batch_dev over 6 lanes" % (n, QUALITY, uniq, SEED), "images_per_step": n},
+                               "kpeg_hip_decode_batch_dev (the batch as restart segments of one virtual stream: one set of launches)" % (n, QUALITY, uniq, SEED), "images_per_step": n},
         "images_per_s": round(n / res["lanes"], 1), "us_per_image": round(res["lanes"] / n * 1e6, 2),
         "one_stream": {"value": round(mp / res["one_stream"], 2), "us_per_image": round(res["one_stream"] / n * 1e6, 2)},
     }), flush=True)
@@ -167,7 +167,7 @@ def main():
                          "(off by default so that a rocprofv3 summary of the default command holds the headline workload only)")
     ap.add_argument("--batch", type=int, default=0,
                     help="BASELINE config 4 instead of the headline: N synthetic 1920x1080 images (seeds 1234..), device-resident, "
-                         "kpeg_hip_decode_batch_dev (six lanes) beside the one-stream loop; one step = the whole batch")
+                         "kpeg_hip_decode_batch_dev (fused launches) beside the one-stream loop; one step = the whole batch")
     args = ap.parse_args()
 
     import torch

@@ -131,7 +131,9 @@ int kpeg_hip_decode_scan_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const u
 int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* d_scan, size_t scan_len,
                                uint32_t first_mcu_row, uint32_t mcu_rows, uint8_t* d_rgb);
 /* kpeg_hip_decode_batch with device-resident scans and outputs (arrays of device pointers held on the
- * host): asynchronous; the context's stream continues behind all lanes, errors surface at kpeg_hip_sync(). */
+ * host; rgb buffers 16-byte aligned): the images are decoded as the restart segments of one virtual
+ * stream, i.e. by ONE set of kernel launches per chunk of up to 4096 images / 256 MiB of scan data.
+ * Asynchronous on the context's stream for a single chunk; errors surface at kpeg_hip_sync(). */
 int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpeg_frame* frame, const uint8_t* const* d_scans,
                               const size_t* scan_lens, uint8_t* const* d_rgbs);
 /* Entropy decode only: d_coef receives the coefficient layout of kpeg_hip_idct_colour. */

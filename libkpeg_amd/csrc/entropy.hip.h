@@ -217,6 +217,14 @@ struct EntropyLaunch {
     int num_cus;
     int sync_passes;   // 0 = default
     int warm;          // warm-up sub-sequences per workgroup, < 0 = default (test hook: 0 makes every workgroup guess wrong)
+    // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
+    // from the known state, DC predictors reset): d_scan / scan_len are unused, restart_interval = MCUs per image
+    uint32_t nimg = 0;
+    const uint8_t* const* d_scan_tab = nullptr;  // [nimg] device pointers (device array)
+    const uint32_t* d_len_tab = nullptr;         // [nimg] scan lengths
+    const uint32_t* d_wg_tab = nullptr;          // [nimg + 1] first K0 workgroup of each image
+    uint32_t total_parts = 0;                    // K0 workgroups over all images
+    uint64_t total_len = 0;                      // scan bytes over all images
 };
 
 // ------------------------------------------------------------------------------------------
@@ -265,15 +273,34 @@ __device__ __forceinline__ void us_flags(const uint32_t w[4], uint32_t prev, uin
 // workgroup knows the totals; without restart markers it also does k_seg_setup's job (one segment), which
 // saves that launch.  part[] must be zero on entry: K1's last launch clears it for the next call.
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PFX = 2ull << 62;
+struct UnstuffBatch {   // nimg > 0: workgroup g belongs to the image whose [wg_tab[i], wg_tab[i+1]) holds g
+    uint32_t nimg;
+    const uint8_t* const* scan_tab;
+    const uint32_t* len_tab;
+    const uint32_t* wg_tab;
+};
 __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
                                                         uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
-                                                        uint32_t nsub_cap, uint32_t* status)
+                                                        uint32_t nsub_cap, uint32_t* status, UnstuffBatch bt)
 {
     __shared__ uint32_t s_wave[US_THREADS / 64];
     __shared__ uint32_t s_base[2];
     __shared__ uint32_t s_out[US_BLOCK_BYTES / 4 + 2];
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t j0 = (g * US_THREADS + t) * US_BYTES_PER_THREAD;
+    uint32_t gl = g, img = 0;   // workgroup index inside its image
+    if (bt.nimg) {
+        uint32_t lo = 0, hi = bt.nimg;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (bt.wg_tab[mid] <= g) lo = mid;
+            else hi = mid;
+        }
+        img = lo;
+        gl = g - bt.wg_tab[img];
+        b = bt.scan_tab[img];
+        n = bt.len_tab[img];
+    }
+    const uint32_t j0 = (gl * US_THREADS + t) * US_BYTES_PER_THREAD;
     const uint32_t nvalid = j0 >= n ? 0u : min((uint32_t)US_BYTES_PER_THREAD, n - j0);
     uint32_t w[4] = {0, 0, 0, 0};
     if (nvalid == US_BYTES_PER_THREAD && (reinterpret_cast<uintptr_t>(b) & 15) == 0) {
@@ -368,13 +395,14 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         }
     }
     if (g == 0 && t == 0) seg_off[0] = 0;
+    if (bt.nimg && gl == 0 && t == 0 && img < seg_cap) seg_off[img] = base_k;   // image img = segment img of the virtual stream
     if (g == gridDim.x - 1) {
-        const uint32_t n_u = base_k + tk, nseg = s_base[1] + tm + 1;
+        const uint32_t n_u = base_k + tk, nseg = bt.nimg ? bt.nimg : s_base[1] + tm + 1;
         if (t == 0) {
             meta->n_u = n_u;
             meta->nseg = nseg;
         }
-        if (!rst) {
+        if (!rst && !bt.nimg) {
             // one segment: what k_seg_setup does.  Bytes past the end read as zero (the readers look ahead).
             if (t < 16) u[(n_u + t) ^ 3] = 0;
             if (t == 0) {
@@ -1349,13 +1377,14 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     auto mark = [&](int which) {
         if (ev && hipEventRecord(ev[which], L.stream) == hipSuccess) ev_rec[which] = true;
     };
-    if (L.scan_len >= (1ull << 28)) {
-        *err = "entropy-coded segment larger than 256 MiB";
+    const uint64_t len64 = L.nimg ? L.total_len : (uint64_t)L.scan_len;
+    if (len64 >= (1ull << 28)) {
+        *err = "entropy-coded data larger than 256 MiB";
         return KPEG_HIP_E_UNSUPPORTED;
     }
-    const uint32_t n = (uint32_t)L.scan_len;
+    const uint32_t n = (uint32_t)len64;
     const uint32_t nseg_expected = L.restart_interval ? (L.nmcu + L.restart_interval - 1) / L.restart_interval : 1;
-    const uint32_t nparts = (n + US_BLOCK_BYTES - 1) / US_BLOCK_BYTES;
+    const uint32_t nparts = L.nimg ? L.total_parts : (n + US_BLOCK_BYTES - 1) / US_BLOCK_BYTES;
     const uint32_t nsub_cap = (uint32_t)(((uint64_t)n * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS) + nseg_expected + 1;
     const uint32_t seg_cap = nseg_expected + 2;
     const uint32_t nwg_cap = (nsub_cap + OWN - 1) / OWN;
@@ -1389,12 +1418,18 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     uint32_t* done = (uint32_t*)(bslot + nwg_cap);
     int4* cnt = (int4*)S->d_cnt;
     int4* prefix = cnt + nsub_cap;
-    const int rst = L.restart_interval ? 1 : 0;
+    const int rst = L.restart_interval ? 1 : 0;   // restart segments (markers in the stream, or the images of a fused batch)
+    const int markers = rst && !L.nimg;            // K0 strips RSTn
+    UnstuffBatch bt;
+    bt.nimg = L.nimg;
+    bt.scan_tab = L.d_scan_tab;
+    bt.len_tab = L.d_len_tab;
+    bt.wg_tab = L.d_wg_tab;
 
     if (!S->part_clean) ENT_HIP(hipMemsetAsync(S->d_part, 0, S->part_cap, L.stream));
     S->part_clean = false;
-    hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, rst, (unsigned long long*)S->d_part,
-                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status);
+    hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, markers, (unsigned long long*)S->d_part,
+                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt);
     if (rst)
         hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, L.stream, S->d_meta, seg_off, sub_base, seg_cap, nsub_cap,
                            (uint8_t*)S->d_u, nseg_expected, L.d_status);

@@ -75,6 +75,8 @@ struct IdctParams {
     uint32_t skip_exact;  // timing experiments only: count unsafe pixels but do not re-evaluate them
     uint32_t* status;     // the call's status words (device): stats == status + 16, [3] = wavefronts of this launch that are done
     uint32_t* h_status;   // host-pinned mirror (device address) or null: the launch's last wavefront copies the device words to it and clears them
+    uint8_t* const* rgb_table;  // fused batch: output base of every image (device array), else null and rgb is the base
+    uint32_t rows_per_img;      // ... MCU rows per image
     uint32_t keep_status; // batch lanes: leave the device words standing (error flags and counters accumulate over the lane's images)
 };
 
@@ -582,7 +584,13 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
-        uint8_t* base = p.rgb + (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
+        uint8_t* base;
+        if (p.rgb_table) {   // wave-uniform
+            const uint32_t img = trow / p.rows_per_img;
+            base = p.rgb_table[img] + (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch + (size_t)m0 * 24;
+        } else {
+            base = p.rgb + (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
+        }
         if (nm == TILE_MCUS && pitch16) {
 #ifdef KPEG_ABLATE_STORES
             if (p.ntiles == 1) *reinterpret_cast<uint4*>(base + wbA_g) = *reinterpret_cast<const uint4*>(s_tile + wbA_lds);

@@ -30,6 +30,7 @@ struct kpeg_hip_ctx {
     int idct_mode = 0;
     int sync_passes = 0;  // 0 = default number of enqueued sync passes
     int warm = -1;        // test hook: K1's warm-up sub-sequences per workgroup (< 0 = default)
+    int batch_chunk = 4096;  // images per fused-batch chunk (test hook: small values exercise the chunk loop)
     bool profiling = false;
     int num_cus = 256;
 
@@ -68,6 +69,10 @@ struct kpeg_hip_ctx {
     bool lanes_pending = false;            // parent: lanes hold deferred status
     bool keep_status = false;              // lane, during a batch: the device status words accumulate over the lane's images
     void* h_scan = nullptr;                // lane: pinned staging for host-buffer batches
+    void* d_batch = nullptr;               // fused batch: descriptor blob (pointer tables, lengths)
+    size_t batch_cap = 0;
+    void* h_batch = nullptr;               // ... its pinned staging
+    size_t h_batch_cap = 0;
     size_t h_scan_cap = 0;
 };
 
@@ -167,6 +172,8 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
         if (ctx->lane_ev[l]) (void)hipEventDestroy(ctx->lane_ev[l]);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
+    if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     if (ctx->d_coef) (void)hipFree(ctx->d_coef);
     if (ctx->d_scan) (void)hipFree(ctx->d_scan);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
@@ -294,7 +301,8 @@ static void natural_qtables(const kpeg_frame* f, QTables* qt)
 }
 
 // K4 launch: rows [0, mcu_rows) of d_coef -> d_rgb.  ctx->d_ebound must hold the blocks' error bounds.
-static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_coef, uint8_t* d_rgb, uint32_t mcu_rows)
+static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_coef, uint8_t* d_rgb, uint32_t mcu_rows,
+                       uint8_t* const* d_rgb_table = nullptr, uint32_t rows_per_img = 0)
 {
     if ((reinterpret_cast<uintptr_t>(d_coef) & 15) || (reinterpret_cast<uintptr_t>(d_rgb) & 7)) {
         ctx->last_error = "device coefficient buffer must be 16-byte aligned, rgb buffer 8-byte aligned";
@@ -313,6 +321,8 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     p.status = ctx->d_status;
     p.h_status = ctx->idct_mode == 1 ? nullptr : ctx->h_status_dev;   // the per-MCU exact kernel has no epilogue
     p.keep_status = ctx->keep_status ? 1u : 0u;
+    p.rgb_table = d_rgb_table;
+    p.rows_per_img = rows_per_img;
     p.skip_exact = ctx->idct_mode == 2;
     if (ctx->idct_mode == 1) {
         p.tiles_w = 0;
@@ -403,7 +413,7 @@ extern "C" int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
 // Entropy decode + IDCT
 
 static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint32_t nmcu,
-                       int16_t* d_coef)
+                       int16_t* d_coef, const EntropyLaunch* batch = nullptr)
 {
     EntropyTables tabs;
     int rc = build_entropy_tables(f, &tabs);
@@ -424,6 +434,15 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.num_cus = ctx->num_cus;
     L.sync_passes = ctx->sync_passes;
     L.warm = ctx->warm;
+    if (batch) {
+        L.nimg = batch->nimg;
+        L.d_scan_tab = batch->d_scan_tab;
+        L.d_len_tab = batch->d_len_tab;
+        L.d_wg_tab = batch->d_wg_tab;
+        L.total_parts = batch->total_parts;
+        L.total_len = batch->total_len;
+        L.restart_interval = batch->restart_interval;
+    }
     hipEvent_t* evs = ctx->profiling ? ctx->ev : nullptr;
     rc = entropy_decode_launch(&ctx->ent, tabs, L, evs, ctx->ev_rec, &ctx->last_error);
     return rc;
@@ -543,6 +562,93 @@ static int lanes_join(kpeg_hip_ctx* ctx)
     return KPEG_HIP_OK;
 }
 
+// Fused batch: the images of a chunk are decoded as the restart segments of one virtual stream -- every
+// segment starts from the known state with its DC predictors reset, which is exactly what an independent
+// image needs -- so one set of launches covers them all (K0 gathers the scans through a pointer table,
+// K4 scatters the rows through another).  Launch gaps and half-empty grids are what small images cost on
+// their own; fused, a batch of 1080p images runs at the rate of one large image.
+static int decode_batch_fused(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f, const uint8_t* const* d_scans, const size_t* scan_lens,
+                              uint8_t* const* d_rgbs)
+{
+    const uint32_t nmcu1 = (f->width / 8) * (f->height / 8);
+    int done = 0;
+    while (done < count) {
+        // a chunk: as many images as fit 256 MiB of scan data, 2^27 blocks and 4096 segments
+        int n = 0;
+        uint64_t bytes = 0;
+        while (done + n < count && n < ctx->batch_chunk && (uint64_t)(n + 1) * nmcu1 * 3 < (1ull << 27)) {
+            const size_t len = scan_lens[done + n];
+            if (!d_scans[done + n] || !d_rgbs[done + n] || len == 0) return KPEG_HIP_E_ARG;
+            if ((reinterpret_cast<uintptr_t>(d_rgbs[done + n]) & 15) || len >= (1ull << 28)) {
+                ctx->last_error = "batch: rgb buffers must be 16-byte aligned, scans below 256 MiB";
+                return KPEG_HIP_E_ARG;
+            }
+            if (bytes + len >= (1ull << 28)) break;
+            bytes += len;
+            ++n;
+        }
+        if (n == 0) {
+            ctx->last_error = "batch: image too large for the fused path";
+            return KPEG_HIP_E_UNSUPPORTED;
+        }
+        // descriptor blob: [n] scan pointers, [n] rgb pointers, [n] lengths, [n + 1] first K0 workgroup
+        const size_t blob = (size_t)n * 16 + (size_t)n * 4 + (size_t)(n + 1) * 4;
+        int rc;
+        if ((rc = grow(ctx, &ctx->d_batch, &ctx->batch_cap, blob))) return rc;
+        if (blob > ctx->h_batch_cap) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+            ctx->h_batch = nullptr;
+            ctx->h_batch_cap = 0;
+            HIPCHK(ctx, hipHostMalloc(&ctx->h_batch, blob * 2, hipHostMallocDefault));
+            ctx->h_batch_cap = blob * 2;
+        } else {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the previous chunk's upload has left the staging buffer
+        }
+        uint8_t* hb = (uint8_t*)ctx->h_batch;
+        const uint8_t** h_scan = (const uint8_t**)hb;
+        uint8_t** h_rgb = (uint8_t**)(hb + (size_t)n * 8);
+        uint32_t* h_len = (uint32_t*)(hb + (size_t)n * 16);
+        uint32_t* h_wg = h_len + n;
+        uint32_t parts = 0;
+        for (int i = 0; i < n; ++i) {
+            h_scan[i] = d_scans[done + i];
+            h_rgb[i] = d_rgbs[done + i];
+            h_len[i] = (uint32_t)scan_lens[done + i];
+            h_wg[i] = parts;
+            parts += (h_len[i] + US_BLOCK_BYTES - 1) / US_BLOCK_BYTES;
+        }
+        h_wg[n] = parts;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_batch, ctx->h_batch, blob, hipMemcpyHostToDevice, ctx->stream));
+        const uint8_t* db = (const uint8_t*)ctx->d_batch;
+        EntropyLaunch B;
+        B.nimg = (uint32_t)n;
+        B.d_scan_tab = (const uint8_t* const*)db;
+        B.d_len_tab = (const uint32_t*)(db + (size_t)n * 16);
+        B.d_wg_tab = B.d_len_tab + n;
+        B.total_parts = parts;
+        B.total_len = bytes;
+        B.restart_interval = nmcu1;
+        const size_t nmcu = (size_t)nmcu1 * n;
+        if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
+        begin_call(ctx);
+        if (!ctx->status_clean) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+        ctx->status_clean = false;
+        rc = run_entropy(ctx, f, nullptr, 0, (uint32_t)nmcu, (int16_t*)ctx->d_coef, &B);
+        if (rc) return rc;
+        rc = launch_idct(ctx, f, (const int16_t*)ctx->d_coef, nullptr, (uint32_t)(f->height / 8) * n, (uint8_t* const*)(db + (size_t)n * 8),
+                         f->height / 8);
+        if (rc) return rc;
+        if ((rc = finish_async(ctx, true))) return rc;
+        done += n;
+        if (done < count) {
+            // the next chunk reuses the scratch and would overwrite the status words: settle this one first
+            if ((rc = kpeg_hip_sync(ctx))) return rc;
+        }
+    }
+    return KPEG_HIP_OK;
+}
+
 extern "C" int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f, const uint8_t* const* d_scans,
                                          const size_t* scan_lens, uint8_t* const* d_rgbs)
 {
@@ -550,6 +656,7 @@ extern "C" int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpe
     if (rc) return rc;
     if (count <= 0 || !d_scans || !scan_lens || !d_rgbs) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!f->restart_interval && ctx->idct_mode != 1) return decode_batch_fused(ctx, count, f, d_scans, scan_lens, d_rgbs);
     if ((rc = ensure_lanes(ctx))) return rc;
     if ((rc = lanes_fork(ctx))) return rc;
     for (int i = 0; i < count; ++i) {
@@ -617,12 +724,14 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
     return kpeg_hip_sync(ctx);
 }
 
-// test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default)
+// test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default),
+// key 3 = images per fused-batch chunk (0 = default)
 extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
 {
     if (!ctx) return KPEG_HIP_E_ARG;
     if (key == 1) ctx->sync_passes = value;
     else if (key == 2) ctx->warm = value;
+    else if (key == 3) ctx->batch_chunk = value > 0 && value <= 4096 ? value : 4096;
     else return KPEG_HIP_E_ARG;
     return KPEG_HIP_OK;
 }

@@ -255,6 +255,30 @@ def test_decode_batch(ctx):
     assert np.array_equal(ctx.decode_scan(parsed[3][1], parsed[3][2]), outs[3])
 
 
+@pytest.mark.parametrize("chunk", [0, 4])
+def test_decode_batch_dev_fused(ctx, chunk):
+    """Device-resident batch = the images as restart segments of one virtual stream, one set of launches
+    (and, with the chunk size forced down by the test hook, several chunks)."""
+    import torch
+    import libkpeg_amd as K
+    w, h, n = 320, 136, 11
+    datas = [T.synth_jpeg(w, h, seed=300 + i, quality=80, sigma=1.0 + i) for i in range(n)]
+    parsed = [K.host_parse(d) for d in datas]
+    frame = parsed[0][1]
+    d_scans = [torch.from_numpy(np.ascontiguousarray(p[2])).cuda() for p in parsed]
+    d_rgbs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    try:
+        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 3, chunk) == 0
+        ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans], [t.numel() for t in d_scans], [t.data_ptr() for t in d_rgbs])
+        ctx.sync()
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 3, 0)
+    for d, o in zip(datas, d_rgbs):
+        st, want = T.oracle_decode(d)
+        assert np.array_equal(o.cpu().numpy(), want)
+
+
 def test_decode_batch_dev_and_error(ctx):
     """Device-resident batch on the caller's stream; a truncated scan in the middle fails the batch at sync()
     while the other images are still decoded."""
