@@ -112,10 +112,11 @@ int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8
                          uint8_t* rgb);
 
 /* `count` independent images of identical geometry and tables (throughput mode, BASELINE config 4; the
- * reference's counterpart is a loop over JPEGDecoder::decodeImageFile, src/main.cpp:19-33).  Images go
- * round-robin to six internal lanes (stream + scratch each): uploads, kernels and downloads of
- * neighbouring images overlap.  Returns after the last pixel is in rgbs[]; a stream error of any image
- * fails the call (kpeg_hip_last_error names the lane's diagnosis). */
+ * reference's counterpart is a loop over JPEGDecoder::decodeImageFile, src/main.cpp:19-33).  Chunks of
+ * images alternate between two internal lanes (stream + buffers + pinned staging each): a chunk's scans go
+ * up in one copy and are decoded by the fused batch path (see kpeg_hip_decode_batch_dev) while the
+ * previous chunk is downloaded into rgbs[].  Returns after the last pixel is in rgbs[]; a stream error of
+ * any image fails the call (kpeg_hip_last_error names the chunk). */
 int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_frame* frame, const uint8_t* const* scans,
                           const size_t* scan_lens, uint8_t* const* rgbs);
 

@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/kpeg_hip.h"
 #include "entropy.hip.h"
@@ -57,9 +58,9 @@ struct kpeg_hip_ctx {
     bool status_pending = false;
     uint32_t status_seen[KPEG_STATUS_WORDS] = {};   // what the last kpeg_hip_sync read (test hook)
 
-    // throughput mode (kpeg_hip_decode_batch*): independent images go round-robin to NLANES child contexts,
-    // each with its own stream and scratch, so that one image's latency-bound entropy kernels overlap
-    // another's IDCT and the launch gaps of small images overlap each other
+    // child contexts (stream + scratch each) for the batch entry points: the host-buffer batch alternates chunks
+    // between two of them; a device batch outside the fused path's contract (restart markers inside the images)
+    // goes round-robin over all
 #ifndef KPEG_LANES
 #define KPEG_LANES 6
 #endif
@@ -677,51 +678,77 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
     int rc = check_frame(ctx, f);
     if (rc) return rc;
     if (count <= 0 || !scans || !scan_lens || !rgbs) return KPEG_HIP_E_ARG;
+    for (int i = 0; i < count; ++i)
+        if (!scans[i] || !scan_lens[i] || !rgbs[i]) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (f->restart_interval || ctx->idct_mode == 1) {
+        // outside the fused path's contract: one by one
+        for (int i = 0; i < count; ++i)
+            if ((rc = kpeg_hip_decode_scan(ctx, f, scans[i], scan_lens[i], rgbs[i]))) return rc;
+        return KPEG_HIP_OK;
+    }
     if ((rc = ensure_lanes(ctx))) return rc;
-    if ((rc = lanes_fork(ctx))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // Chunks of images alternate between two lanes (stream + buffers + pinned staging each): a chunk's scans
+    // go up in one copy and are decoded by the fused batch path; while the host sits in the (blocking)
+    // downloads of the previous chunk into the caller's pageable buffers, the GPU decodes this one.
     const size_t rbytes = (size_t)f->width * f->height * 3;
-    const int NL = kpeg_hip_ctx::NLANES;
-    // Software pipeline over the lanes: image i is uploaded (through the lane's pinned staging, so the copy
-    // is truly asynchronous) and its kernels are enqueued; the download of image i - (NL - 1), whose kernels
-    // have had that long to finish, is issued afterwards.  A download into pageable memory blocks the
-    // host, which is exactly when the other lanes' kernels run.
-    auto download = [&](int j) -> int {
-        kpeg_hip_ctx* c = ctx->lanes[j % NL];
-        HIPCHK(ctx, hipMemcpyAsync(rgbs[j], c->d_rgb, rbytes, hipMemcpyDeviceToHost, c->stream));
+    const int per_chunk = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)192 << 20) / rbytes));
+    struct Chunk { int first = 0, n = 0; };
+    Chunk prev;
+    bool have_prev = false;
+    auto download = [&](const Chunk& c, int lane) -> int {
+        kpeg_hip_ctx* L = ctx->lanes[lane];
+        int r = kpeg_hip_sync(L);   // decode finished, status checked
+        if (r) {
+            ctx->last_error = "batch images " + std::to_string(c.first) + ".." + std::to_string(c.first + c.n - 1) + ": " + L->last_error;
+            return r;
+        }
+        for (int i = 0; i < c.n; ++i)
+            HIPCHK(ctx, hipMemcpyAsync(rgbs[c.first + i], (uint8_t*)L->d_rgb + (size_t)i * rbytes, rbytes, hipMemcpyDeviceToHost, L->stream));
+        HIPCHK(ctx, hipStreamSynchronize(L->stream));
         return KPEG_HIP_OK;
     };
-    for (int i = 0; i < count; ++i) {
-        kpeg_hip_ctx* c = ctx->lanes[i % NL];
-        if (!scans[i] || !scan_lens[i] || !rgbs[i]) return KPEG_HIP_E_ARG;
-        if ((rc = grow(c, &c->d_scan, &c->scan_cap, scan_lens[i] + 64))) return rc;
-        if ((rc = grow(c, &c->d_rgb, &c->rgb_cap, rbytes))) return rc;
-        if (scan_lens[i] > c->h_scan_cap) {
-            HIPCHK(ctx, hipStreamSynchronize(c->stream));
-            if (c->h_scan) (void)hipHostFree(c->h_scan);
-            c->h_scan = nullptr;
-            c->h_scan_cap = 0;
-            const size_t want = scan_lens[i] + scan_lens[i] / 4 + 4096;
-            HIPCHK(ctx, hipHostMalloc(&c->h_scan, want, hipHostMallocDefault));
-            c->h_scan_cap = want;
+    int lane = 0;
+    for (int first = 0; first < count; first += per_chunk, lane ^= 1) {
+        Chunk c;
+        c.first = first;
+        c.n = std::min(per_chunk, count - first);
+        kpeg_hip_ctx* L = ctx->lanes[lane];
+        L->idct_mode = ctx->idct_mode;
+        size_t total = 0;
+        std::vector<size_t> off(c.n);
+        for (int i = 0; i < c.n; ++i) {
+            off[i] = total;
+            total += (scan_lens[first + i] + 63) & ~(size_t)63;
         }
-        // the lane's previous image (i - NL) has been downloaded: its stream is past the staging buffer's last use
-        if (i >= NL) HIPCHK(ctx, hipStreamSynchronize(c->stream));
-        std::memcpy(c->h_scan, scans[i], scan_lens[i]);
-        HIPCHK(ctx, hipMemcpyAsync(c->d_scan, c->h_scan, scan_lens[i], hipMemcpyHostToDevice, c->stream));
-        rc = kpeg_hip_decode_scan_dev(c, f, (const uint8_t*)c->d_scan, scan_lens[i], (uint8_t*)c->d_rgb);
+        if ((rc = grow(L, &L->d_scan, &L->scan_cap, total + 64))) return rc;
+        if ((rc = grow(L, &L->d_rgb, &L->rgb_cap, rbytes * c.n))) return rc;
+        if (total > L->h_scan_cap) {
+            if (L->h_scan) (void)hipHostFree(L->h_scan);
+            L->h_scan = nullptr;
+            L->h_scan_cap = 0;
+            HIPCHK(ctx, hipHostMalloc(&L->h_scan, total + total / 4 + 4096, hipHostMallocDefault));
+            L->h_scan_cap = total + total / 4 + 4096;
+        }
+        std::vector<const uint8_t*> dsc(c.n);
+        std::vector<uint8_t*> drg(c.n);
+        for (int i = 0; i < c.n; ++i) {
+            std::memcpy((uint8_t*)L->h_scan + off[i], scans[first + i], scan_lens[first + i]);
+            dsc[i] = (const uint8_t*)L->d_scan + off[i];
+            drg[i] = (uint8_t*)L->d_rgb + (size_t)i * rbytes;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(L->d_scan, L->h_scan, total, hipMemcpyHostToDevice, L->stream));
+        rc = decode_batch_fused(L, c.n, f, dsc.data(), scan_lens + first, drg.data());
         if (rc) {
-            ctx->last_error = "batch image " + std::to_string(i) + ": " + c->last_error;
-            (void)lanes_join(ctx);
-            (void)kpeg_hip_sync(ctx);
+            ctx->last_error = "batch images " + std::to_string(first) + "..: " + L->last_error;
             return rc;
         }
-        if (i >= NL - 1 && (rc = download(i - (NL - 1)))) return rc;
+        if (have_prev && (rc = download(prev, lane ^ 1))) return rc;
+        prev = c;
+        have_prev = true;
     }
-    for (int j = count > NL - 1 ? count - (NL - 1) : 0; j < count; ++j)
-        if ((rc = download(j))) return rc;
-    if ((rc = lanes_join(ctx))) return rc;
-    return kpeg_hip_sync(ctx);
+    return download(prev, lane ^ 1);
 }
 
 // test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default),
