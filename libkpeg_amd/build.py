@@ -31,7 +31,7 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-STRESS_DEFS = ["-DKPEG_SUBSEQ_BITS=64", "-DKPEG_SYNC_WG=128", "-DKPEG_WARM_BITS=64"]
+STRESS_DEFS = ["-DKPEG_SUBSEQ_BITS=64", "-DKPEG_SYNC_WG=128", "-DKPEG_WARM_BITS=64", "-DKPEG_POOL_SUBS=2"]
 
 
 def _run(cmd, cwd=None):
@@ -48,7 +48,9 @@ def build_hip(force=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     _run([hipcc] + HIP_FLAGS + ["-o", out, os.path.join(CSRC, "kpeg_hip.hip")])
     # test-only twin with tiny K1/K2 workgroups and a 64-bit warm-up: real streams then need the boundary
-    # passes and the chained pass that the product geometry almost never reaches (tests/test_gpu_decode.py)
+    # passes and the chained pass that the product geometry almost never reaches; and a pool of two
+    # second-level Huffman tables, so that the Annex-K tables overflow it and long codes take the
+    # canonical-search fallback (tests/test_gpu_decode.py)
     _run([hipcc] + HIP_FLAGS + STRESS_DEFS + ["-o", os.path.join(PKG, "libkpeg_hip_stress.so"), os.path.join(CSRC, "kpeg_hip.hip")])
     return out
 

@@ -88,7 +88,8 @@ def test_boundary_passes_and_chained_pass_on_tiny_workgroups():
     """libkpeg_hip_stress.so = the same sources with 127 x 64-bit sub-sequences per workgroup and a 64-bit
     warm-up (libkpeg_amd/build.py): dense noise re-synchronises over many of those workgroups, so the
     verifying passes leave work and the chained last pass has to end the ripple.  Product geometry
-    (64-Kbit workgroups) practically never gets there."""
+    (48-Kbit workgroups) practically never gets there.  The same build has a pool of only two second-level
+    Huffman tables: the long codes of the Annex-K tables take the canonical-search fallback."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
