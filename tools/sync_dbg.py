@@ -16,9 +16,8 @@ rgb = ctx.decode_scan(frame, scan)
 out = (ctypes.c_uint32 * 16)()
 ctx.lib.kpeg_hip_debug_words(ctx._h, out, 16)
 w = list(out)
-nwg = (len(scan) * 8 + 255) // 256 // 256 + 1
+nwg = w[11]
 print("words", w)
-print("WG rounds: sum %d max %d (~%d WGs -> mean %.2f)" % (w[8], w[9], nwg, w[8] / nwg))
-print("round 0: waves %d mean max-lane iterations %.1f" % (w[11], w[10] / max(1, w[11])))
-print("jacobi: active wave-rounds %d, mean iterations %.1f, total wave-iterations %d (round 0 total %d)" % (w[13], w[12] / max(1, w[13]), w[12], w[10]))
-print("pass 0 per workgroup (s_memtime ticks): setup %.0f  round 0 %.0f  later rounds %.0f" % (w[13] * 16 / max(1, w[11] // 2), w[14] * 16 / max(1, w[11] // 2), w[15] * 16 / max(1, w[11] // 2)))
+print("pass 0: %d workgroups, rounds per workgroup mean %.2f max %d" % (nwg, w[8] / max(1, nwg), w[9]))
+print("sub-sequence decodes %d, symbol steps %d (%.1f per decode)" % (w[10], w[12], w[12] / max(1, w[10])))
+print("per workgroup (s_memtime ticks): setup %.0f  round 0 %.0f  later rounds %.0f" % (w[13] * 16 / max(1, nwg), w[14] * 16 / max(1, nwg), w[15] * 16 / max(1, nwg)))
