@@ -367,6 +367,17 @@ def main():
             "kernels_ms": {k: round(v, 5) for k, v in tm.items() if k.endswith("_ms")},
             "sync_passes": tm.get("sync_rounds"), "exact_pixels_per_image": tm.get("exact_pixels"),
         }
+        if not args.idct_only:
+            # per-kernel and end-to-end achieved GB/s from algorithmic bytes (this rank's stripe):
+            # K0 reads and writes the scan once, K1 reads it (its rounds run from LDS), K2 reads it and writes 6 B/pixel
+            # of coefficients, K4 reads those and writes 3 B/pixel; fused minimum = scan in + 3 B/pixel out
+            S, px = float(d_scan.numel()), float(W * H)
+            def gbs(nbytes, ms):
+                return round(nbytes / (ms * 1e-3) / 1e9, 1) if ms and ms > 0 else None
+            out["algorithmic_GBs"] = {
+                "K0_unstuff": gbs(2 * S, tm.get("unstuff_ms")), "K1_sync": gbs(S, tm.get("huff_sync_ms")),
+                "K2_write": gbs(S + 6 * px, tm.get("huff_write_ms")), "K4_idct_colour": gbs(9 * px, tm.get("idct_ms")),
+                "end_to_end_fused_minimum": gbs((S + 3 * px) * world, ms_per_step)}
         if stress:
             out["stress"] = stress
         if gather:
