@@ -110,6 +110,7 @@ struct EntropyTables {  // built on the host per frame, copied to the device whe
     uint8_t zz[64];                  // zig-zag -> natural
     float mscale_zz[2][64];          // 0.25 * cc[u][v] * Q[u][v] by zig-zag position: K4's input scale
     float q00[2];                    // Q[0][0] of both tables
+    float pad16[2];                  // (the tables are copied to LDS in 16-byte pieces)
 };
 
 static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
@@ -526,6 +527,7 @@ struct LdsTables {
     uint8_t zz[64];
     float mscale_zz[2][64];
     float q00[2];
+    float pad16[2];
 };
 static_assert(sizeof(LdsTables) - sizeof(uint32_t) * 6 * (1 << LUT_BITS) == sizeof(EntropyTables) - sizeof(uint32_t) * 4 * (1 << LUT_BITS),
               "layout after the first-level tables");
@@ -534,13 +536,19 @@ __device__ __forceinline__ uint32_t slot_table(uint32_t slot) { return (slot & 1
 
 __device__ __forceinline__ void load_tables(LdsTables* dst, const EntropyTables* src)
 {
-    uint32_t* l = &dst->lut[0][0];
-    for (uint32_t i = threadIdx.x; i < (6u << LUT_BITS); i += blockDim.x)
-        l[i] = src->lut[slot_table(i >> LUT_BITS)][i & ((1u << LUT_BITS) - 1)];
-    const uint32_t* s = &src->pool[0][0];
-    uint32_t* d = &dst->pool[0][0];
-    constexpr uint32_t n = (sizeof(EntropyTables) - sizeof(uint32_t) * 4 * (1 << LUT_BITS)) / 4;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    // 16 bytes per load: 26 KB per workgroup, a few loads per thread (hipMalloc'd source, 16-byte aligned members)
+    constexpr uint32_t LUT_V4 = (1u << LUT_BITS) / 4;   // uint4 per first-level table
+    uint4* l = reinterpret_cast<uint4*>(&dst->lut[0][0]);
+    for (uint32_t i = threadIdx.x; i < 6 * LUT_V4; i += blockDim.x) {
+        const uint32_t slot = i / LUT_V4;
+        l[i] = reinterpret_cast<const uint4*>(&src->lut[slot_table(slot)][0])[i - slot * LUT_V4];
+    }
+    constexpr uint32_t nbytes = sizeof(EntropyTables) - sizeof(uint32_t) * 4 * (1 << LUT_BITS);
+    static_assert(nbytes % 16 == 0 && (sizeof(uint32_t) * 4 * (1 << LUT_BITS)) % 16 == 0 && (sizeof(uint32_t) * 6 * (1 << LUT_BITS)) % 16 == 0,
+                  "tables are copied in 16-byte pieces");
+    const uint4* s = reinterpret_cast<const uint4*>(&src->pool[0][0]);
+    uint4* d = reinterpret_cast<uint4*>(&dst->pool[0][0]);
+    for (uint32_t i = threadIdx.x; i < nbytes / 16; i += blockDim.x) d[i] = s[i];
 }
 
 // The bit string as the decode loops see it: the workgroup's slice staged in LDS.  Every position
@@ -816,7 +824,7 @@ __device__ void wsum_scan(int4* wsum, EntropyMeta* meta, uint32_t* status, int p
 //   state re-decodes from that state and the change ripples on.
 __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 {
-    __shared__ LdsTables T;
+    __shared__ __attribute__((aligned(16))) LdsTables T;
     __shared__ uint64_t s_X[ITEMS + 1];
     __shared__ uint32_t s_geo[ITEMS + 1];   // pend | first-of-its-segment << 31
     __shared__ int4 s_cnt[SYNC_WG];
@@ -1114,7 +1122,7 @@ struct WriteArgs {
 // block nobody settles (corrupt stream) is still decoded correctly.
 __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
 {
-    __shared__ LdsTables T;
+    __shared__ __attribute__((aligned(16))) LdsTables T;
     __shared__ int4 s_pre[SYNC_WG];   // first the scan of cnt, then every lane's share of the block open at its exit
     constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
