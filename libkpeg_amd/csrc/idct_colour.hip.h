@@ -610,35 +610,11 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
 
     uint32_t prev_tile = 0xFFFFFFFFu;
     uint32_t nq_total = 0;
-#ifdef KPEG_K4_PREFETCH
-    uint4 nd0 = make_uint4(0, 0, 0, 0), nd1 = nd0, nd2 = nd0;
-    float ne0 = 0.f, ne1 = 0.f, ne2 = 0.f;
-    if (blockIdx.x < p.ntiles) {
-        const size_t nmcu = tile_mcu(blockIdx.x);
-        const uint4* nsrc = reinterpret_cast<const uint4*>(p.coef) + nmcu * 24 + u;
-        nd0 = nsrc[0], nd1 = nsrc[8], nd2 = nsrc[16];
-        ne0 = p.ebound[nmcu * 3], ne1 = p.ebound[nmcu * 3 + 1], ne2 = p.ebound[nmcu * 3 + 2];
-    }
-#endif
     for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
         const bool active = (uint32_t)grp < nm;
-#ifdef KPEG_K4_PREFETCH
-        // software prefetch: this tile's data was requested one iteration ago
-        const uint4 d0 = nd0, d1 = nd1, d2 = nd2;
-        const float e0 = ne0, e1 = ne1, e2 = ne2;
-        {
-            const uint32_t nt = tile + gridDim.x;
-            if (nt < p.ntiles) {
-                const size_t nmcu = tile_mcu(nt);
-                const uint4* nsrc = reinterpret_cast<const uint4*>(p.coef) + nmcu * 24 + u;
-                nd0 = nsrc[0], nd1 = nsrc[8], nd2 = nsrc[16];
-                ne0 = p.ebound[nmcu * 3], ne1 = p.ebound[nmcu * 3 + 1], ne2 = p.ebound[nmcu * 3 + 2];
-            }
-        }
-#else
         const size_t mcu = tile_mcu(tile);
 #ifdef KPEG_ABLATE_LOADS
         const uint4 d0 = make_uint4(tile, tid, 0, 0), d1 = make_uint4(tid, 0, 0, 0), d2 = make_uint4(tile & 3, 0, 0, 0);
@@ -647,7 +623,6 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         const uint4* src = reinterpret_cast<const uint4*>(p.coef) + mcu * 24 + u;
         const uint4 d0 = src[0], d1 = src[8], d2 = src[16];
         const float e0 = p.ebound[mcu * 3], e1 = p.ebound[mcu * 3 + 1], e2 = p.ebound[mcu * 3 + 2];
-#endif
 #endif
 
         if (prev_tile != 0xFFFFFFFFu) write_back(prev_tile);  // LDS still holds the previous tile
