@@ -162,6 +162,9 @@ def main():
                     help="N>1 dry run on a one-GPU box: gloo backend, every rank on cuda:0 (the driver's runs use RCCL, one GPU per rank)")
     ap.add_argument("--idct-mode", type=int, default=0, help="kpeg_hip_set_idct_mode (2 = timing experiment, wrong pixels)")
     ap.add_argument("--idct-only", action="store_true", help="time K4 alone on resident coefficients (BASELINE config 2 style)")
+    ap.add_argument("--restart-stripe", action="store_true",
+                    help="N=1 only: decode the workload the N>1 ranks get (restart interval = one MCU row, DRI extension) instead of "
+                         "the reference-compatible stream; tells what part of the N>1 per-rank time the restart machinery costs")
     ap.add_argument("--side-figures", action="store_true",
                     help="also report SURVEY 8(d)'s side figures: measured device-copy ceiling and the dense q95 noise stress input "
                          "(off by default so that a rocprofv3 summary of the default command holds the headline workload only)")
@@ -198,7 +201,7 @@ def main():
     W, H = args.width, args.height
     mw, mh = W // 8, H // 8
     # ---- input: this rank's stripe of the (virtual) W x (H*world) image -------------------
-    if world == 1:
+    if world == 1 and not args.restart_stripe:
         data = synth_jpeg(W, H)
         rc, frame, scan = K.host_parse(data)
         assert rc == K.DECODE_DONE, rc
@@ -360,7 +363,7 @@ def main():
             "config": {"workload": ("K4 only, " if args.idct_only else "") +
                        "%dx%d 4:4:4 baseline JPEG q%d, seed %d, %s" % (
                            W, H * world, QUALITY, SEED,
-                           "no restart markers, full on-device Huffman + IDCT" if world == 1 else
+                           "no restart markers, full on-device Huffman + IDCT" if world == 1 and not args.restart_stripe else
                            "restart interval = 1 MCU row, %d row stripes of %d rows, one per GPU" % (world, H)),
                        "scan_bytes_per_gpu": int(d_scan.numel()), "pixels_per_step": pixels_per_step},
             "roofline": roof,
