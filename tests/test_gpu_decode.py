@@ -51,6 +51,17 @@ def test_decode_scan_matches_oracle(ctx, w, h, q, sigma, smode):
     assert bad.size == 0, "first mismatches (y,x,c): %s of %d" % (bad[:8].tolist(), len(bad))
 
 
+@pytest.mark.parametrize("w,h", [(65528, 8), (16, 65528), (8000, 16), (24, 24), (4104, 40)])
+def test_extreme_geometries(ctx, w, h):
+    """One MCU row of the maximum width, one MCU column of the maximum height, widths that leave a partial K4 tile."""
+    data = T.synth_jpeg(w, h, seed=77)
+    st, want = T.oracle_decode(data)
+    assert st == T.DECODE_DONE
+    p = T.oracle_parse(data)
+    got = ctx.decode_scan(T.make_frame(p), p.scan)
+    assert np.array_equal(got, want)
+
+
 def test_flat_image(ctx):
     """A constant image is a periodic bit string (14 bits per MCU: DC diff 0 + EOB, three times)."""
     rgb = np.empty((1024, 2048, 3), np.uint8)
