@@ -190,7 +190,7 @@ struct EntropyScratch {
     bool part_clean = false;    // d_part is all zero (the previous call's last K1 launch cleared what that call used)
     void* d_segoff = nullptr;   size_t seg_cap = 0;     // seg_off[S+1], sub_base[S+1]
     void* d_state = nullptr;    size_t state_cap = 0;   // X[nsub], Xb[2][nwg], assumed[nwg] uint64
-    void* d_cnt = nullptr;      size_t cnt_cap = 0;     // cnt[nsub] int4, prefix[nsub] int4
+    void* d_cnt = nullptr;      size_t cnt_cap = 0;     // cnt[nsub] int4
     void* d_wsum = nullptr;     size_t wsum_cap = 0;
     EntropyMeta* d_meta = nullptr;
     EntropyTables* d_tabs = nullptr;
@@ -1064,28 +1064,6 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// materialised exclusive prefix (only needed when restart segments re-base it)
-__global__ __launch_bounds__(SYNC_WG) void k_scan_apply(const int4* cnt, const int4* wsum, const EntropyMeta* meta, int4* prefix)
-{
-    __shared__ int4 s[SYNC_WG];
-    const uint32_t nsub = meta->nsub;
-    uint32_t i = blockIdx.x * OWN + threadIdx.x;
-    if (blockIdx.x * OWN >= nsub) return;
-    const bool valid = threadIdx.x < OWN && i < nsub;
-    int4 v = valid ? cnt[i] : make_int4(0, 0, 0, 0);
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < SYNC_WG; o <<= 1) {
-        int4 t = make_int4(0, 0, 0, 0);
-        if ((int)threadIdx.x >= o) t = s[threadIdx.x - o];
-        __syncthreads();
-        s[threadIdx.x] = add4(s[threadIdx.x], t);
-        __syncthreads();
-    }
-    int4 incl = s[threadIdx.x], w = wsum[blockIdx.x];
-    if (valid) prefix[i] = make_int4(w.x + incl.x - v.x, w.y + incl.y - v.y, w.z + incl.z - v.z, w.w + incl.w - v.w);
-}
-
 // ------------------------------------------------------------------------------------------
 // K2: write pass
 struct WriteArgs {
@@ -1097,7 +1075,6 @@ struct WriteArgs {
     const uint64_t* X;   // [nsub_cap] converged exit states
     const int4* cnt;     // per-sub-sequence (blocks started, dc sums)
     const int4* wsum;    // exclusive prefix of the per-workgroup totals
-    const int4* prefix;  // materialised exclusive prefix (restart segments only, else null)
     int16_t* coef;       // cleared by K1's pass 0
     float* ebound;       // [block] K4's per-block error bound
     uint32_t nsub_cap;
@@ -1124,6 +1101,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
 {
     __shared__ __attribute__((aligned(16))) LdsTables T;
     __shared__ int4 s_pre[SYNC_WG];   // first the scan of cnt, then every lane's share of the block open at its exit
+    __shared__ int4 s_wred[SYNC_WG / 64];
     constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
     const uint32_t nsub = a.meta->nsub;
@@ -1133,13 +1111,14 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     const uint32_t i = i0 + threadIdx.x;
     const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
     const uint32_t nseg = a.meta->nseg;
-    const uint32_t w0 = sub_geom(a.seg_off, a.sub_base, nseg, i0).pstart >> 5;
+    const SubGeom g0 = sub_geom(a.seg_off, a.sub_base, nseg, i0);
+    const uint32_t w0 = g0.pstart >> 5;
     {
         const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
-    if (!a.prefix) {
-        // single segment: exclusive scan of cnt inside the workgroup + the workgroup's offset
+    // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup ...
+    {
         int4 v = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
         s_pre[threadIdx.x] = v;
         __syncthreads();
@@ -1150,9 +1129,28 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             s_pre[threadIdx.x] = add4(s_pre[threadIdx.x], t);
             __syncthreads();
         }
-        int4 incl = s_pre[threadIdx.x], w = a.wsum[blockIdx.x];
+        const int4 incl = s_pre[threadIdx.x];
         __syncthreads();
-        s_pre[threadIdx.x] = make_int4(w.x + incl.x - v.x, w.y + incl.y - v.y, w.z + incl.z - v.z, w.w + incl.w - v.w);
+        s_pre[threadIdx.x] = make_int4(incl.x - v.x, incl.y - v.y, incl.z - v.z, incl.w - v.w);
+    }
+    // ... + the workgroup's offset, counted from the start of the restart segment.  A segment that began in
+    // this workgroup re-bases on a neighbour's scan value; the one open at the workgroup's first
+    // sub-sequence began in an earlier workgroup: its base is that workgroup's offset + its cnt up to there.
+    int4 open_base = make_int4(0, 0, 0, 0);
+    if (nseg > 1 && g0.li != 0) {
+        const uint32_t first0 = a.sub_base[g0.seg], gf = first0 / OWN, lf = first0 - gf * OWN;
+        int4 part = make_int4(0, 0, 0, 0);
+        for (uint32_t j = threadIdx.x; j < lf; j += SYNC_WG) part = add4(part, a.cnt[gf * OWN + j]);
+        for (int o = 32; o > 0; o >>= 1) {
+            part.x += __shfl_down(part.x, o);
+            part.y += __shfl_down(part.y, o);
+            part.z += __shfl_down(part.z, o);
+            part.w += __shfl_down(part.w, o);
+        }
+        if ((threadIdx.x & 63) == 0) s_wred[threadIdx.x >> 6] = part;
+        __syncthreads();
+        open_base = a.wsum[gf];
+        for (int q = 0; q < SYNC_WG / 64; ++q) open_base = add4(open_base, s_wred[q]);
     }
     __syncthreads();
 
@@ -1170,7 +1168,6 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     int tail_chroma = 0;
     constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
     int4 pre = make_int4(0, 0, 0, 0);
-    if (!a.prefix) pre = s_pre[threadIdx.x];
     if (valid) {
         const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, i);
         DecState s;
@@ -1184,10 +1181,16 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         }
         // block index and DC predictors at entry, relative to the segment start
         const uint32_t first = a.sub_base[g.seg];
-        if (a.prefix) {
-            if (g.li != 0) {
-                int4 pi = a.prefix[i], p0 = a.prefix[first];
-                pre = make_int4(pi.x - p0.x, pi.y - p0.y, pi.z - p0.z, pi.w - p0.w);
+        if (g.li != 0) {
+            const int4 loc = s_pre[threadIdx.x];
+            if (nseg == 1) {
+                pre = add4(a.wsum[blockIdx.x], loc);
+            } else if (first >= i0) {
+                const int4 f = s_pre[first - i0];
+                pre = make_int4(loc.x - f.x, loc.y - f.y, loc.z - f.z, loc.w - f.w);
+            } else {
+                const int4 w = a.wsum[blockIdx.x];
+                pre = make_int4(w.x + loc.x - open_base.x, w.y + loc.y - open_base.y, w.z + loc.z - open_base.z, w.w + loc.w - open_base.w);
             }
         }
         const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
@@ -1405,7 +1408,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     }
     if ((rc = ent_grow(&S->d_segoff, &S->seg_cap, (size_t)seg_cap * 2 * sizeof(uint32_t), L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 5 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
-    if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 32, L.stream, err))) return rc;
+    if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 16, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_wsum, &S->wsum_cap, ((size_t)nwg_cap + 2) * 16, L.stream, err))) return rc;
     if (!S->d_meta) ENT_HIP(hipMalloc((void**)&S->d_meta, sizeof(EntropyMeta)));
     if (!S->d_tabs) ENT_HIP(hipMalloc((void**)&S->d_tabs, sizeof(EntropyTables)));
@@ -1425,7 +1428,6 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     unsigned long long* bslot = (unsigned long long*)(assumed + nwg_cap);
     uint32_t* done = (uint32_t*)(bslot + nwg_cap);
     int4* cnt = (int4*)S->d_cnt;
-    int4* prefix = cnt + nsub_cap;
     const int rst = L.restart_interval ? 1 : 0;   // restart segments (markers in the stream, or the images of a fused batch)
     const int markers = rst && !L.nimg;            // K0 strips RSTn
     UnstuffBatch bt;
@@ -1473,9 +1475,6 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     }
     mark(2);
 
-    if (rst)
-        hipLaunchKernelGGL(k_scan_apply, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, (const int4*)cnt, (const int4*)S->d_wsum,
-                           (const EntropyMeta*)S->d_meta, prefix);
     mark(3);
 
     WriteArgs wa;
@@ -1487,7 +1486,6 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     wa.X = X;
     wa.cnt = cnt;
     wa.wsum = (const int4*)S->d_wsum;
-    wa.prefix = rst ? prefix : nullptr;
     wa.coef = L.d_coef;
     wa.ebound = L.d_ebound;
     wa.nsub_cap = nsub_cap;
