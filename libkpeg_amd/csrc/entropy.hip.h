@@ -182,6 +182,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t moved[SYNC_PASSES + 8];  // per pass >= 1: workgroups whose last exit state moved
     uint32_t total_blocks;
     uint32_t ticket;   // workgroups that have finished the chained pass
+    uint32_t k0_slot[64], k0_top;   // K0's two-level ticket (restart segments: the last workgroup to finish sets the segments up)
 };
 
 struct EntropyScratch {
@@ -274,6 +275,71 @@ __device__ __forceinline__ void us_flags(const uint32_t w[4], uint32_t prev, uin
 // workgroup knows the totals; without restart markers it also does k_seg_setup's job (one segment), which
 // saves that launch.  part[] must be zero on entry: K1's last launch clears it for the next call.
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PFX = 2ull << 62;
+// Restart segments (RSTn markers, or the images of a fused batch): seg_off[nseg] = n_u, bytes past the end
+// zeroed, sub_base[] = exclusive scan of ceil(seg_bits / SUBSEQ_BITS), bookkeeping reset.  Run by the last
+// workgroup of k_unstuff to finish (US_THREADS threads); seg_off[] was written by other workgroups of the
+// same launch, hence the L2 loads.
+__device__ void seg_setup_wg(EntropyMeta* meta, uint32_t* seg_off, uint32_t* sub_base, uint32_t seg_cap, uint32_t nsub_cap, uint8_t* u,
+                             uint32_t n_u, uint32_t nseg, uint32_t expected_segs, uint32_t* status, uint32_t* s /* [US_THREADS] */, uint32_t* carry)
+{
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        meta->n_u = n_u;
+        meta->nseg = nseg;
+        for (int i = 0; i < SYNC_PASSES + 8; ++i) meta->moved[i] = 0;
+        meta->total_blocks = 0;
+        meta->ticket = 0;
+    }
+    if (nseg != expected_segs || nseg + 1 > seg_cap) {
+        if (t == 0) {
+            atomicOr(&status[1], 1u);  // restart markers do not match the restart interval
+            meta->nsub = 0;
+        }
+        return;
+    }
+    if (t == 0) {
+        seg_off[nseg] = n_u;
+        *carry = 0;
+    }
+    if (t < 16) u[(n_u + t) ^ 3] = 0;   // bytes past the end read as zero (the readers look ahead)
+    __syncthreads();
+    auto seg_at = [&](uint32_t r) -> uint32_t {
+        return r == nseg ? n_u : __hip_atomic_load(&seg_off[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (uint32_t base = 0; base < nseg; base += US_THREADS) {
+        const uint32_t r = base + t;
+        uint32_t v = 0;
+        if (r < nseg) {
+            const uint32_t bits = (seg_at(r + 1) - seg_at(r)) * 8;
+            v = (bits + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
+            if (v == 0) v = 1;
+        }
+        s[t] = v;
+        __syncthreads();
+        for (int o = 1; o < US_THREADS; o <<= 1) {
+            uint32_t x = 0;
+            if ((int)t >= o) x = s[t - o];
+            __syncthreads();
+            s[t] += x;
+            __syncthreads();
+        }
+        const uint32_t c = *carry;
+        if (r < nseg) sub_base[r] = c + s[t] - v;
+        __syncthreads();
+        if (t == US_THREADS - 1) *carry = c + s[US_THREADS - 1];
+        __syncthreads();
+    }
+    if (t == 0) {
+        sub_base[nseg] = *carry;
+        if (*carry > nsub_cap) {
+            atomicOr(&status[1], 2u);
+            meta->nsub = 0;
+        } else {
+            meta->nsub = *carry;
+        }
+    }
+}
+
 struct UnstuffBatch {   // nimg > 0: workgroup g belongs to the image whose [wg_tab[i], wg_tab[i+1]) holds g
     uint32_t nimg;
     const uint8_t* const* scan_tab;
@@ -282,10 +348,11 @@ struct UnstuffBatch {   // nimg > 0: workgroup g belongs to the image whose [wg_
 };
 __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
                                                         uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
-                                                        uint32_t nsub_cap, uint32_t* status, UnstuffBatch bt)
+                                                        uint32_t nsub_cap, uint32_t* status, UnstuffBatch bt, uint32_t expected_segs)
 {
     __shared__ uint32_t s_wave[US_THREADS / 64];
     __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_dep, s_last;
     __shared__ uint32_t s_out[US_BLOCK_BYTES / 4 + 2];
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint32_t gl = g, img = 0;   // workgroup index inside its image
@@ -355,13 +422,15 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         }
         if (lane == 0) {
             const unsigned long long acc = (unsigned long long)acc_k | ((unsigned long long)acc_m << 28);
-            __hip_atomic_store(&part[g], (acc + mine) | LB_PFX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (an exchange: its return means it has been performed, which the ticket at the end relies on)
+            s_dep = (uint32_t)atomicExch(&part[g], (acc + mine) | LB_PFX);
             s_base[0] = acc_k;
             s_base[1] = acc_m;
         }
     }
     __syncthreads();
     const uint32_t base_k = s_base[0], abase = base_k & ~3u;
+    uint32_t dep = 0;   // values returned by this thread's segment-offset exchanges
     {
         const uint32_t excl = woff + v - own;
         uint32_t pos = base_k + (excl & 0xFFFF);
@@ -371,7 +440,7 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         for (int k = 0; k < US_BYTES_PER_THREAD; ++k) {
             if (mm & (1u << k)) {
                 mk++;
-                if (mk < seg_cap) seg_off[mk] = pos;  // segment mk starts at the next kept byte
+                if (mk < seg_cap) dep |= atomicExch(&seg_off[mk], pos);  // segment mk starts at the next kept byte
             }
             if (km & (1u << k)) {
                 so[(pos - abase) ^ 3] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));  // big-endian words for little-endian 32-bit loads
@@ -395,18 +464,16 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
             }
         }
     }
-    if (g == 0 && t == 0) seg_off[0] = 0;
-    if (bt.nimg && gl == 0 && t == 0 && img < seg_cap) seg_off[img] = base_k;   // image img = segment img of the virtual stream
-    if (g == gridDim.x - 1) {
-        const uint32_t n_u = base_k + tk, nseg = bt.nimg ? bt.nimg : s_base[1] + tm + 1;
-        if (t == 0) {
-            meta->n_u = n_u;
-            meta->nseg = nseg;
-        }
-        if (!rst && !bt.nimg) {
-            // one segment: what k_seg_setup does.  Bytes past the end read as zero (the readers look ahead).
-            if (t < 16) u[(n_u + t) ^ 3] = 0;
+    if (g == 0 && t == 0) dep |= atomicExch(&seg_off[0], 0u);
+    if (bt.nimg && gl == 0 && t == 0 && img < seg_cap) dep |= atomicExch(&seg_off[img], base_k);   // image img = segment img of the virtual stream
+    if (!rst && !bt.nimg) {
+        if (g == gridDim.x - 1) {
+            // one segment, and this workgroup knows the total: the set-up in place
+            const uint32_t n_u = base_k + tk;
+            if (t < 16) u[(n_u + t) ^ 3] = 0;   // bytes past the end read as zero (the readers look ahead)
             if (t == 0) {
+                meta->n_u = n_u;
+                meta->nseg = 1;
                 uint32_t nsub = (n_u * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
                 if (nsub == 0) nsub = 1;
                 seg_off[1] = n_u;
@@ -422,70 +489,28 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
                 meta->ticket = 0;
             }
         }
-    }
-}
-
-// single workgroup: seg_off[nseg] = n_u, zero the padding words, sub_base[] = exclusive scan
-// of ceil(seg_bits / SUBSEQ_BITS)
-__global__ __launch_bounds__(1024) void k_seg_setup(EntropyMeta* meta, uint32_t* seg_off, uint32_t* sub_base, uint32_t seg_cap,
-                                                    uint32_t nsub_cap, uint8_t* u, uint32_t expected_segs, uint32_t* status)
-{
-    __shared__ uint32_t s[1024];
-    __shared__ uint32_t carry;
-    const uint32_t n_u = meta->n_u;
-    uint32_t nseg = meta->nseg;
-    if (nseg != expected_segs || nseg + 1 > seg_cap) {
-        if (threadIdx.x == 0) {
-            atomicOr(&status[1], 1u);  // restart markers do not match the restart interval
-            meta->nsub = 0;
-        }
         return;
     }
-    if (threadIdx.x == 0) {
-        seg_off[nseg] = n_u;
-        carry = 0;
-    }
-    // bytes past the end read as zero (the reader may look 8 bytes ahead)
-    if (threadIdx.x < 16) {
-        uint32_t j = (n_u + threadIdx.x);
-        // only the bytes beyond n_u inside the last partially written word and two more words
-        u[j ^ 3] = 0;
+    // Restart segments: their offsets come from many workgroups, so the last one to finish sets them up.
+    // Two-level ticket (a thousand tickets on one word queue up at the kernel's tail); no fences (a release
+    // fence writes back the whole L2): every write the set-up reads is an exchange whose return this
+    // workgroup has waited for.
+    if (dep == 0xDEADBEEFu && t == 1) s_dep ^= dep;   // (keeps the returned values live: the exchanges are waited for)
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t slot = g & 63, in_slot = (gridDim.x - slot + 63) >> 6;
+        uint32_t last = 0;
+        if (atomicAdd(&meta->k0_slot[slot], 1u + (s_dep & 0u)) == in_slot - 1)
+            last = atomicAdd(&meta->k0_top, 1u) == min(gridDim.x, 64u) - 1 ? 1u : 0u;
+        s_last = last;
     }
     __syncthreads();
-    for (uint32_t base = 0; base < nseg; base += 1024) {
-        uint32_t r = base + threadIdx.x;
-        uint32_t v = 0;
-        if (r < nseg) {
-            uint32_t bits = (seg_off[r + 1] - seg_off[r]) * 8;
-            v = (bits + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
-            if (v == 0) v = 1;
-        }
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            uint32_t t = 0;
-            if ((int)threadIdx.x >= o) t = s[threadIdx.x - o];
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        uint32_t c = carry;
-        if (r < nseg) sub_base[r] = c + s[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + s[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        sub_base[nseg] = carry;
-        if (carry > nsub_cap) {
-            atomicOr(&status[1], 2u);
-            meta->nsub = 0;
-        } else {
-            meta->nsub = carry;
-        }
-        for (int i = 0; i < SYNC_PASSES + 8; ++i) meta->moved[i] = 0;
-        meta->total_blocks = 0;
-        meta->ticket = 0;
+    if (s_last) {
+        const unsigned long long tot = __hip_atomic_load(&part[gridDim.x - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n_u = (uint32_t)(tot & 0xFFFFFFFu), nseg = bt.nimg ? bt.nimg : (uint32_t)((tot >> 28) & 0x7FFFFFFu) + 1;
+        seg_setup_wg(meta, seg_off, sub_base, seg_cap, nsub_cap, u, n_u, nseg, expected_segs, status, s_out, &s_base[0]);
+        if (t < 64) meta->k0_slot[t] = 0;
+        if (t == 64) meta->k0_top = 0;
     }
 }
 
@@ -1410,7 +1435,10 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 5 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 16, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_wsum, &S->wsum_cap, ((size_t)nwg_cap + 2) * 16, L.stream, err))) return rc;
-    if (!S->d_meta) ENT_HIP(hipMalloc((void**)&S->d_meta, sizeof(EntropyMeta)));
+    if (!S->d_meta) {
+        ENT_HIP(hipMalloc((void**)&S->d_meta, sizeof(EntropyMeta)));
+        ENT_HIP(hipMemset(S->d_meta, 0, sizeof(EntropyMeta)));   // K0's tickets start at zero and are left at zero
+    }
     if (!S->d_tabs) ENT_HIP(hipMalloc((void**)&S->d_tabs, sizeof(EntropyTables)));
     if (!S->tabs_valid || std::memcmp(&S->h_tabs_cached, &tabs, sizeof(tabs)) != 0) {
         // tables changed: earlier launches may still read the old ones
@@ -1439,10 +1467,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     if (!S->part_clean) ENT_HIP(hipMemsetAsync(S->d_part, 0, S->part_cap, L.stream));
     S->part_clean = false;
     hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, markers, (unsigned long long*)S->d_part,
-                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt);
-    if (rst)
-        hipLaunchKernelGGL(k_seg_setup, dim3(1), dim3(1024), 0, L.stream, S->d_meta, seg_off, sub_base, seg_cap, nsub_cap,
-                           (uint8_t*)S->d_u, nseg_expected, L.d_status);
+                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt, nseg_expected);
     mark(1);
 
     SyncArgs sa;
