@@ -61,7 +61,7 @@ def synth_jpeg(w, h, y0=0, restart_interval=0, seed=SEED, quality=QUALITY, sigma
     return buf[:n].tobytes()
 
 
-def cpu_baseline(sample_w=2560, sample_h=1440):
+def cpu_baseline(sample_w=3840, sample_h=2160):
     """Reference CPU decoder on a bounded crop (top-left sample_w x sample_h of the 8K field)."""
     data = synth_jpeg(sample_w, sample_h)
     mp = sample_w * sample_h / 1e6
