@@ -1295,8 +1295,11 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                 if (F & F_STARTED) {
                     // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
                     const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
+                    // even mantissa, rounded up; lowest bit = chroma samples may leave the f32 colour range (Asum >= 249)
+                    const uint32_t Eb = ((__float_as_uint(E) + 1u) & ~1u) | ((tdc && !(Asum < 249.0f)) ? 1u : 0u);
+                    const float Ef = __uint_as_float(Eb);
 #if KPEG_ABLATE_W != 3
-                    a.ebound[gb] = !(Asum < (tdc ? 249.0f : 31000.0f)) ? __builtin_inff() : ((F & F_NONCORNER) ? E : -E);
+                    a.ebound[gb] = !(Asum < 31000.0f) ? __builtin_inff() : ((F & F_NONCORNER) ? Ef : -Ef);
 #else
                     if (E == 123.0f) a.ebound[gb] = E;
 #endif
@@ -1337,7 +1340,8 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     };
     auto settle = [&](uint32_t blk, float A, int n, bool crn, int chroma) {
         const float E = n ? (0x1.004p-24f * A) * ((float)n + 14.5f) : 0.0f;
-        if (A < (chroma ? 249.0f : 31000.0f)) a.ebound[blk] = crn ? -E : E;   // else the preset +inf stands
+        const float Ef = __uint_as_float(((__float_as_uint(E) + 1u) & ~1u) | ((chroma && !(A < 249.0f)) ? 1u : 0u));
+        if (A < 31000.0f) a.ebound[blk] = crn ? -Ef : Ef;   // else the preset +inf stands
     };
     const uint32_t nown = min((uint32_t)OWN, nsub - i0);
     const bool tail = threadIdx.x == nown - 1 && (share.z & SH_OPEN);   // the workgroup's last lane leaves a block open

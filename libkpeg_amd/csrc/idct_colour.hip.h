@@ -247,21 +247,27 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
 // |t - rint(t)| below this sends the G channel to the exact path (f32 error of t <= 3.7e-5)
 #define KPEG_G_DELTA 6.0e-5f
 
-// Range guard folded into the bound: every fast sample satisfies |v| <= A (1 + 2^-20), so a block
-// whose A stays below the limit cannot leave the range the f32 colour arithmetic (chroma, |.| < 250)
-// or the queue's int16 fields (|.| < 32000) are proven for.  A block at or above the limit gets
-// E = +inf: all its samples take the reference-order path.
+// Range guards folded into the bound: every fast sample satisfies |v| <= A (1 + 2^-20).
+//   A >= KPEG_A_LIM (any component): the queue's int16 fields (|.| < 32000) could overflow: E = +inf, all the
+//       block's samples take the reference-order path.
+//   A >= KPEG_A_LIM_CHROMA (chroma block): the samples may leave the range the f32 colour arithmetic is proven
+//       for (|.| < 250): the lowest mantissa bit of E is set (E is first rounded up to an even mantissa, so the
+//       bit never shrinks it) and K4 converts that MCU's pixels with the reference's double arithmetic in-lane.
+//       Saturated colour edges do this in photographs; dense noise does it everywhere.
 #define KPEG_A_LIM_CHROMA 249.0f
-#define KPEG_A_LIM_LUMA 31000.0f
+#define KPEG_A_LIM 31000.0f
 // The sign bit carries one more fact about the block: set = every non-zero AC coefficient sits at
 // (0,1), (1,0) or (1,1).  Those blocks produce nearly all true ties (equal and opposite (0,1)/(1,0)
 // terms cancel on the diagonal), and their reference-order sum has at most four terms, which the
 // lane that found the tie evaluates itself (exact_corner) instead of queueing the pixel.
 __device__ __forceinline__ float block_ebound(float A, int nnz_ac, bool chroma, bool corner_only)
 {
-    if (!(A < (chroma ? KPEG_A_LIM_CHROMA : KPEG_A_LIM_LUMA))) return __builtin_inff();
+    if (!(A < KPEG_A_LIM)) return __builtin_inff();
     const float E = nnz_ac ? (KPEG_U * A) * ((float)nnz_ac + KPEG_KAPPA) : 0.0f;
-    return corner_only ? -E : E;
+    uint32_t bits = (__float_as_uint(E) + 1u) & ~1u;
+    if (chroma && !(A < KPEG_A_LIM_CHROMA)) bits |= 1u;
+    const float Ef = __uint_as_float(bits);
+    return corner_only ? -Ef : Ef;
 }
 
 // E for caller-supplied coefficients (kpeg_hip_idct_colour): one thread per block.
@@ -655,6 +661,9 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
 #endif
         const float thr0 = 0.5f - fabsf(e0), thr1 = 0.5f - fabsf(e1), thr2 = 0.5f - fabsf(e2);
         const bool sp0 = __float_as_uint(e0) >> 31, sp1 = __float_as_uint(e1) >> 31, sp2 = __float_as_uint(e2) >> 31;
+        // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
+        const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
+        const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
 
         // Level shift + colour for the 8 pixels of this lane's row.  Per pixel one float key says
         // whether the reference-order evaluation is needed (key >= 0): a fast value within its block's
@@ -690,13 +699,23 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 }
             }
             const float yf = ry + 128.0f;
-            const float R = yf + floorf(rr * 1.402f);
-            const float B = yf + floorf(rb * 1.772f);
+            float R = yf + floorf(rr * 1.402f);
+            float B = yf + floorf(rb * 1.772f);
             const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
-            const float G = yf - ceilf(t);
+            float G = yf - ceilf(t);
             // distance of t to the nearest integer, except that t == 0 (Cb = Cr = 128, exact in the
             // reference too) must not count: non-zero |t| is >= 8e-6, so 1 - |t| * 2^17 <= 0 there
-            const float dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
+            float dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
+            if (any_wide) {
+                if (wide) {
+                    // out of the f32 colour arithmetic's range: the reference's own double arithmetic on the rounded samples
+                    const uint32_t px = colour_exact((int)ry + 128, (int)rb + 128, (int)rr + 128);
+                    R = (float)(px & 0xFF);
+                    G = (float)((px >> 8) & 0xFF);
+                    B = (float)(px >> 16);
+                    dt = 1.0f;   // G is exact here
+                }
+            }
             const float key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
             pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
             pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);

@@ -49,7 +49,8 @@ def test_kernel_error_constant_covers_the_derived_bound():
     # K2 writes the same bound formula as block_ebound()
     ent = open(os.path.join(CSRC, "entropy.hip.h")).read()
     assert "(0x1.004p-24f * Asum) * ((float)nnz + %sf)" % ("%.1f" % kk) in ent
-    assert "Asum < (tdc ? 249.0f : 31000.0f)" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM_LUMA 31000.0f" in src
+    assert "Asum < 249.0f" in ent and "Asum < 31000.0f" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM 31000.0f" in src
+    assert "(__float_as_uint(E) + 1u) & ~1u" in ent and "(__float_as_uint(E) + 1u) & ~1u" in src   # same flag encoding on both sides
     assert "#define KPEG_U 0x1.004p-24f" in src
 
 
