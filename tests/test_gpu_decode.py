@@ -200,6 +200,21 @@ def test_golden_fixtures_through_the_product_path(ctx):
         assert T.sha256(T.ppm_bytes(rgb)) == g["ppm_sha256"], name
 
 
+def test_lena_through_the_cli(tmp_path):
+    """The reference's own sample image (misc/images/lena.jpg, committed as a data fixture): `kpeg lena.jpg` must
+    write the PPM whose SHA-256 SURVEY.md section 4 records for the reference decoder."""
+    import json, os, shutil, subprocess
+    import libkpeg_amd as K
+    man = json.load(open(os.path.join(T.GOLDEN, "manifest.json")))["lena"]
+    src = os.path.join(T.GOLDEN, man["fixture"])
+    assert T.sha256(open(src, "rb").read()) == man["jpg_sha256"]
+    dst = tmp_path / "lena.jpg"
+    shutil.copy(src, dst)
+    out = subprocess.run([K.CLI, str(dst)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-500:]
+    assert T.sha256(open(tmp_path / "lena.ppm", "rb").read()) == man["ppm_sha256"] == "064dace1c86b7d2d887ae5d2b76fc53444136e155cc45cf2bad867fcdb13078d"
+
+
 def test_cli_writes_the_reference_ppm(tmp_path):
     """`kpeg <file.jpg>` -> <file>.ppm, byte-identical to the reference CLI's output."""
     import json, os, shutil, subprocess
