@@ -675,37 +675,17 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         uint32_t nq = 0;
         const uint32_t ent_lane = (uint32_t)grp | ((uint32_t)lane8 << 5);
         const unsigned long long active_mask = __ballot(active);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
-            float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
-            float fy = fabsf(vy - ry) - thr0, fb = fabsf(vb - rb) - thr1, fr = fabsf(vr - rr) - thr2;
-            // a fast value within its block's bound of a rounding boundary (>= 0): corner-only blocks are
-            // settled here in reference order, the others stay flagged for the queue
-            if (__builtin_amdgcn_fcmpf(fmaxf(fy, fmaxf(fb, fr)), 0.0f, 3 /* OGE */) & active_mask) {  // wave-uniform
-                const double cy1 = c_cos[i * 8 + 1];
-                const uint32_t* blk = s_coef + grp * 96;
-                if (fy >= 0.0f && sp0) {
-                    ry = exact_corner(blk[0], blk[4], qy00, qy01, qy10, qy11, cx1, cy1);
-                    fy = -1.0f;
-                }
-                if (fb >= 0.0f && sp1) {
-                    rb = exact_corner(blk[32], blk[36], qc00, qc01, qc10, qc11, cx1, cy1);
-                    fb = -1.0f;
-                }
-                if (fr >= 0.0f && sp2) {
-                    rr = exact_corner(blk[64], blk[68], qc00, qc01, qc10, qc11, cx1, cy1);
-                    fr = -1.0f;
-                }
-            }
+        // colour of one pixel from its three rounded samples (minus the level shift); dt = how far the G
+        // term's t is from an integer, as seen by the f32 arithmetic (1.0 where G needs no check)
+        auto colour_of = [&](float ry, float rb, float rr, float& R, float& G, float& B, float& dt) {
             const float yf = ry + 128.0f;
-            float R = yf + floorf(rr * 1.402f);
-            float B = yf + floorf(rb * 1.772f);
+            R = yf + floorf(rr * 1.402f);
+            B = yf + floorf(rb * 1.772f);
             const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
-            float G = yf - ceilf(t);
+            G = yf - ceilf(t);
             // distance of t to the nearest integer, except that t == 0 (Cb = Cr = 128, exact in the
             // reference too) must not count: non-zero |t| is >= 8e-6, so 1 - |t| * 2^17 <= 0 there
-            float dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
+            dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
             if (any_wide) {
                 if (wide) {
                     // out of the f32 colour arithmetic's range: the reference's own double arithmetic on the rounded samples
@@ -716,23 +696,64 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                     dt = 1.0f;   // G is exact here
                 }
             }
-            const float key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
+        };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
+            float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
+            // >= 0: the fast value is within its block's bound of a rounding boundary
+            float fy = fabsf(vy - ry) - thr0, fb = fabsf(vb - rb) - thr1, fr = fabsf(vr - rr) - thr2;
+            float R, G, B, dt;
+            colour_of(ry, rb, rr, R, G, B, dt);
+            float key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
             pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
             pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
             pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
 #ifndef KPEG_ABLATE_PUSH
-            const bool push = active && key >= 0.0f;
-            const unsigned long long bal = __builtin_amdgcn_fcmpf(key, 0.0f, 3 /* FCMP_OGE */) & active_mask;
-            if (bal) {  // wave-uniform
-                const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                if (push && slot < QUEUE_CAP) {
-                    // entry.x: [2:0] mcu in tile, [7:5] pixel row, [10:8] pixel col, [13:11] components to
-                    // re-evaluate, [31:16] rint(vY); entry.y: rint(vCb) | rint(vCr) << 16 (all |.| < 32000)
-                    const uint32_t mask = (fy >= 0.0f ? 1u : 0u) | (fb >= 0.0f ? 2u : 0u) | (fr >= 0.0f ? 4u : 0u);
-                    s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (mask << 11) | ((uint32_t)(int)ry << 16),
-                                               ((uint32_t)(int)rb & 0xFFFFu) | ((uint32_t)(int)rr << 16));
+            // one wave-uniform test per pixel column: nobody flagged -> next column
+            if (__builtin_amdgcn_fcmpf(key, 0.0f, 3 /* FCMP_OGE */) & active_mask) {
+                // corner-only blocks are settled here in reference order, by the lane that found the tie
+                bool fixed = false;
+                {
+                    const double cy1 = c_cos[i * 8 + 1];
+                    const uint32_t* blk = s_coef + grp * 96;
+                    if (fy >= 0.0f && sp0) {
+                        ry = exact_corner(blk[0], blk[4], qy00, qy01, qy10, qy11, cx1, cy1);
+                        fy = -1.0f;
+                        fixed = true;
+                    }
+                    if (fb >= 0.0f && sp1) {
+                        rb = exact_corner(blk[32], blk[36], qc00, qc01, qc10, qc11, cx1, cy1);
+                        fb = -1.0f;
+                        fixed = true;
+                    }
+                    if (fr >= 0.0f && sp2) {
+                        rr = exact_corner(blk[64], blk[68], qc00, qc01, qc10, qc11, cx1, cy1);
+                        fr = -1.0f;
+                        fixed = true;
+                    }
                 }
-                nq += __popcll(bal);
+                if (fixed) {
+                    colour_of(ry, rb, rr, R, G, B, dt);
+                    key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
+                    pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
+                    pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
+                    pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
+                }
+                // the others are queued for the wavefront (ballot compaction: no atomics, no second pass)
+                const bool push = active && key >= 0.0f;
+                const unsigned long long bal = __ballot(push);
+                if (bal) {  // wave-uniform
+                    const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+                    if (push && slot < QUEUE_CAP) {
+                        // entry.x: [2:0] mcu in tile, [7:5] pixel row, [10:8] pixel col, [13:11] components to
+                        // re-evaluate, [31:16] rint(vY); entry.y: rint(vCb) | rint(vCr) << 16 (all |.| < 32000)
+                        const uint32_t mask = (fy >= 0.0f ? 1u : 0u) | (fb >= 0.0f ? 2u : 0u) | (fr >= 0.0f ? 4u : 0u);
+                        s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (mask << 11) | ((uint32_t)(int)ry << 16),
+                                                   ((uint32_t)(int)rb & 0xFFFFu) | ((uint32_t)(int)rr << 16));
+                    }
+                    nq += __popcll(bal);
+                }
             }
 #else
             (void)key;
