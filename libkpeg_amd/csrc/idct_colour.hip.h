@@ -590,13 +590,17 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
-        uint8_t* base;
+        // (offsets from the kernel argument p.rgb, also in table mode: a pointer loaded from memory has no known
+        // address space and its stores would be flat_store, which LDS waits then wait for)
+        size_t off;
         if (p.rgb_table) {   // wave-uniform
             const uint32_t img = trow / p.rows_per_img;
-            base = p.rgb_table[img] + (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch + (size_t)m0 * 24;
+            off = (size_t)(reinterpret_cast<uintptr_t>(p.rgb_table[img]) - reinterpret_cast<uintptr_t>(p.rgb)) +
+                  (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch + (size_t)m0 * 24;
         } else {
-            base = p.rgb + (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
+            off = (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
         }
+        uint8_t* base = p.rgb + off;
         if (nm == TILE_MCUS && pitch16) {
 #ifdef KPEG_ABLATE_STORES
             if (p.ntiles == 1) *reinterpret_cast<uint4*>(base + wbA_g) = *reinterpret_cast<const uint4*>(s_tile + wbA_lds);
