@@ -586,20 +586,26 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     const uint32_t wbA_lds = wbA_r * TILE_ROW_STRIDE + wbA_k * 16, wbA_g = wbA_r * p.pitch + wbA_k * 16;
     const uint32_t wbB_lds = wbB_r * TILE_ROW_STRIDE + wbB_k * 16, wbB_g = wbB_r * p.pitch + wbB_k * 16;
     const bool pitch16 = ((reinterpret_cast<uintptr_t>(p.rgb) | p.pitch) & 15) == 0;
-    auto write_back = [&](uint32_t tile) {
-        const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
-        const uint32_t m0 = tcol * TILE_MCUS;
-        const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
-        // (offsets from the kernel argument p.rgb, also in table mode: a pointer loaded from memory has no known
-        // address space and its stores would be flat_store, which LDS waits then wait for)
-        size_t off;
+    // Where a tile's pixels go, as an offset from the kernel argument p.rgb -- also in table mode: a pointer
+    // loaded from memory has no known address space, its stores would be flat_store, and LDS waits wait for
+    // those.  Computed when the tile is taken (the table load then travels with the coefficient loads), used
+    // one iteration later by write_back: a load inside write_back would make it wait for the next tile's
+    // coefficients.
+    auto tile_offset = [&](uint32_t trow, uint32_t m0) -> size_t {
         if (p.rgb_table) {   // wave-uniform
             const uint32_t img = trow / p.rows_per_img;
-            off = (size_t)(reinterpret_cast<uintptr_t>(p.rgb_table[img]) - reinterpret_cast<uintptr_t>(p.rgb)) +
-                  (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch + (size_t)m0 * 24;
-        } else {
-            off = (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
+            // scalar load (the index is wave-uniform): a vector load here would sit behind the coefficient loads in
+            // vmcnt order, and the wait for it would be a wait for them
+            unsigned long long ptr;
+            asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(ptr)
+                         : "s"(p.rgb_table), "s"(img * 8u)
+                         : "memory");
+            return (size_t)(ptr - reinterpret_cast<uintptr_t>(p.rgb)) + (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch + (size_t)m0 * 24;
         }
+        return (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
+    };
+    auto write_back = [&](size_t off, uint32_t nm) {
         uint8_t* base = p.rgb + off;
         if (nm == TILE_MCUS && pitch16) {
 #ifdef KPEG_ABLATE_STORES
@@ -618,7 +624,9 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         }
     };
 
-    uint32_t prev_tile = 0xFFFFFFFFu;
+    bool have_prev = false;
+    size_t prev_off = 0;
+    uint32_t prev_nm = 0;
     uint32_t nq_total = 0;
     for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
@@ -635,8 +643,11 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         const float e0 = p.ebound[mcu * 3], e1 = p.ebound[mcu * 3 + 1], e2 = p.ebound[mcu * 3 + 2];
 #endif
 
-        if (prev_tile != 0xFFFFFFFFu) write_back(prev_tile);  // LDS still holds the previous tile
-        prev_tile = tile;
+        const size_t cur_off = tile_offset(trow, m0);
+        if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
+        have_prev = true;
+        prev_off = cur_off;
+        prev_nm = nm;
         {
             // keep the tile's coefficients at hand for the exact path: block (grp, c), row u
             // (plain uint32_t accesses on both sides: no type punning)
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         __builtin_amdgcn_wave_barrier();
         // the next iteration writes this tile back before its own colour phase overwrites the LDS tile
     }
-    if (prev_tile != 0xFFFFFFFFu) write_back(prev_tile);
+    if (have_prev) write_back(prev_off, prev_nm);
     // one fire-and-forget add per wavefront, spread over 256 words (a single hot word serialises in L2)
     uint32_t dep = 0;
     if (tid == 0 && nq_total && p.stats) dep = atomicAdd(&p.stats[blockIdx.x & 255], nq_total);
