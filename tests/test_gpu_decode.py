@@ -306,6 +306,37 @@ def test_decode_batch_dev_fused(ctx, chunk):
         assert np.array_equal(o.cpu().numpy(), want)
 
 
+def test_decode_batch_dev_with_restart_markers(ctx):
+    """Images that carry restart markers themselves (DRI extension) are outside the fused path's contract: the
+    device batch then goes image by image over the context's lanes."""
+    import torch
+    import libkpeg_amd as K
+    w, h, n, interval = 256, 64, 7, 8
+    datas = [T.synth_jpeg(w, h, seed=500 + i, restart_interval=interval) for i in range(n)]
+    wants, parsed = [], []
+    for d in datas:
+        want, p, _ = T.oracle_decode_rst(d, interval)
+        wants.append(want)
+        parsed.append(p)
+    frame = T.make_frame(parsed[0], interval)
+    d_scans = [torch.frombuffer(bytearray(p.scan), dtype=torch.uint8).cuda() for p in parsed]
+    d_rgbs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans], [t.numel() for t in d_scans], [t.data_ptr() for t in d_rgbs])
+    ctx.sync()
+    for want, o in zip(wants, d_rgbs):
+        assert np.array_equal(o.cpu().numpy(), want)
+    # a truncated image fails the batch at sync(); the lanes stay usable
+    lens = [t.numel() for t in d_scans]
+    lens[2] //= 2
+    ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans], lens, [t.data_ptr() for t in d_rgbs])
+    with pytest.raises(RuntimeError):
+        ctx.sync()
+    ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans], [t.numel() for t in d_scans], [t.data_ptr() for t in d_rgbs])
+    ctx.sync()
+    assert np.array_equal(d_rgbs[2].cpu().numpy(), wants[2])
+
+
 def test_decode_batch_dev_and_error(ctx):
     """Device-resident batch on the caller's stream; a truncated scan in the middle fails the batch at sync()
     while the other images are still decoded."""
