@@ -62,6 +62,29 @@ def test_extreme_geometries(ctx, w, h):
     assert np.array_equal(got, want)
 
 
+def test_random_sweep_against_the_oracle(ctx):
+    """Seeded sweep over sizes, qualities, noise levels, dense-noise mode and restart intervals (48 cases)."""
+    rng = np.random.default_rng(20240607)
+    for case in range(48):
+        w, h = int(rng.integers(1, 40)) * 8, int(rng.integers(1, 24)) * 8
+        q = int(rng.choice([10, 30, 50, 75, 90, 95, 100]))
+        mode = int(rng.random() < 0.2)
+        sigma = 0.0 if mode else float(rng.choice([0.0, 2.0, 6.0, 20.0, 60.0]))
+        seed = int(rng.integers(1, 1 << 30))
+        interval = 0 if rng.random() < 0.6 else int(rng.integers(1, max(2, (w // 8) * (h // 8))))
+        data = T.synth_jpeg(w, h, seed=seed, quality=q, sigma=sigma, mode=mode, restart_interval=interval)
+        if interval:
+            want, p, _ = T.oracle_decode_rst(data, interval)
+            frame = T.make_frame(p, interval)
+        else:
+            st, want = T.oracle_decode(data)
+            assert st == T.DECODE_DONE
+            p = T.oracle_parse(data)
+            frame = T.make_frame(p)
+        got = ctx.decode_scan(frame, p.scan)
+        assert np.array_equal(got, want), (case, w, h, q, sigma, mode, seed, interval)
+
+
 def test_flat_image(ctx):
     """A constant image is a periodic bit string (14 bits per MCU: DC diff 0 + EOB, three times)."""
     rgb = np.empty((1024, 2048, 3), np.uint8)
