@@ -52,19 +52,19 @@ namespace kpeg
 
             inline void printCurrPos()
             {
-                std::cout << "Current file pos: 0x" << std::hex << m_pos << std::endl;
+                std::cout << "Current file pos: 0x" << std::hex << pos_ << std::endl;
             }
 
             // ---- additions (off by default, outside the parity contract) ----
             /// Accept DRI / RSTn (the reference rejects them).
-            void setRestartMarkerSupport( bool on ) { m_allowDRI = on; }
+            void setRestartMarkerSupport( bool on ) { allowDRI_ = on; }
             /// Parse only: stop at the seam and leave the tables for frameInfo().
-            void setParseOnly( bool on ) { m_parseOnly = on; }
+            void setParseOnly( bool on ) { parseOnly_ = on; }
             /// Tables and geometry as handed to the GPU path; valid after decodeImageFile().
             bool frameInfo( kpeg_frame* out ) const;
             /// The entropy-coded segment as scanImageData collected it (still byte-stuffed).
-            const std::vector<UInt8>& scanData() const { return m_scan; }
-            Image& image() { return m_image; }
+            const std::vector<UInt8>& scanData() const { return scan_; }
+            Image& image() { return image_; }
             /// Parse an in-memory file instead of open().
             void openMemory( const UInt8* data, std::size_t size, const std::string& name );
 
@@ -85,22 +85,22 @@ namespace kpeg
             void skip( std::size_t n );
 
         private:
-            std::string m_filename;
-            std::vector<UInt8> m_file;
-            std::size_t m_pos;
-            bool m_eof;
-            bool m_isOpen;
+            std::string filename_;
+            std::vector<UInt8> file_;
+            std::size_t pos_;
+            bool eof_;
+            bool isOpen_;
 
-            Image m_image;
-            std::vector<std::vector<UInt16>> m_QTables;
-            HuffmanTable m_huffmanTable[2][2];
-            HuffmanTree m_huffmanTree[2][2];
-            bool m_tableBroken;          // a table layout the reference would corrupt memory on
+            Image image_;
+            std::vector<std::vector<UInt16>> QTables_;
+            HuffmanTable huffmanTable_[2][2];
+            HuffmanTree huffmanTree_[2][2];
+            bool tableBroken_;          // a table layout the reference would corrupt memory on
 
-            std::vector<UInt8> m_scan;   // entropy-coded segment (reference: m_scanData, as bytes)
-            int m_sosCount;
-            UInt32 m_restartInterval;
-            bool m_allowDRI, m_parseOnly;
+            std::vector<UInt8> scan_;   // entropy-coded segment (reference: scanData_, as bytes)
+            int sosCount_;
+            UInt32 restartInterval_;
+            bool allowDRI_, parseOnly_;
     };
 }
 

@@ -62,7 +62,7 @@ namespace kpeg
             const std::string contains( const std::string& huffCode );
 
         private:
-            NodePtr m_root;
+            NodePtr root_;
     };
 }
 

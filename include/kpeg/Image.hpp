@@ -48,14 +48,14 @@ namespace kpeg
             const std::vector<UInt8>& getRGB8() const;
 
         private:
-            std::string  m_filename;
-            PixelPtr     m_pixelPtr;
-            FPixelPtr    m_flPixelPtr;
-            std::string  m_JPEGversion;
-            std::string  m_comment;
-            std::size_t  m_width;
-            std::size_t  m_height;
-            std::vector<UInt8> m_rgb8;
+            std::string  filename_;
+            PixelPtr     pixelPtr_;
+            FPixelPtr    flPixelPtr_;
+            std::string  JPEGversion_;
+            std::string  comment_;
+            std::size_t  width_;
+            std::size_t  height_;
+            std::vector<UInt8> rgb8_;
     };
 
     const std::string valueToBitString( const Int16 value );

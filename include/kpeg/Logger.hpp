@@ -48,9 +48,9 @@ namespace kpeg
 
         private:
             Logger();
-            Level m_logLevel;
-            std::ostream* m_logStream;
-            static std::unique_ptr<Logger> m_instance;
+            Level logLevel_;
+            std::ostream* logStream_;
+            static std::unique_ptr<Logger> instance_;
     };
 
     /// streambuf that forwards every character to two other streambufs
@@ -61,8 +61,8 @@ namespace kpeg
         private:
             virtual int overflow( int c );
             virtual int sync();
-            std::streambuf* m_sb1;
-            std::streambuf* m_sb2;
+            std::streambuf* sb1_;
+            std::streambuf* sb2_;
     };
 
     class TeeStream : public std::ostream
@@ -70,7 +70,7 @@ namespace kpeg
         public:
             TeeStream( std::ostream& o1, std::ostream& o2 );
         private:
-            TeeBuf m_tbuf;
+            TeeBuf tbuf_;
     };
 }
 

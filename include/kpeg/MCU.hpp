@@ -40,9 +40,9 @@ namespace kpeg
             static MCU fromRGB( const UInt8* rgb, std::size_t pitch );
 
         private:
-            CompMatrices m_8x8block;            // after construction: R, G, B
-            static int m_MCUCount;
-            static std::vector<std::vector<UInt16>> m_QTables;
+            CompMatrices blocks_;            // after construction: R, G, B
+            static int MCUCount_;
+            static std::vector<std::vector<UInt16>> QTables_;
             static int DCDiff[3];               // never reset, as in the reference (quirk Q6)
     };
 }

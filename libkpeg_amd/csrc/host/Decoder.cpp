@@ -28,8 +28,8 @@
 namespace kpeg
 {
     JPEGDecoder::JPEGDecoder() :
-        m_pos( 0 ), m_eof( false ), m_isOpen( false ), m_tableBroken( false ), m_sosCount( 0 ), m_restartInterval( 0 ),
-        m_allowDRI( false ), m_parseOnly( false )
+        pos_( 0 ), eof_( false ), isOpen_( false ), tableBroken_( false ), sosCount_( 0 ), restartInterval_( 0 ),
+        allowDRI_( false ), parseOnly_( false )
     {
         LOG(Logger::Level::INFO) << "Created \'JPEGDecoder object\'." << std::endl;
     }
@@ -53,41 +53,41 @@ namespace kpeg
         in.seekg( 0, std::ios::end );
         const std::streamoff n = in.tellg();
         in.seekg( 0, std::ios::beg );
-        m_file.resize( n > 0 ? (std::size_t)n : 0 );
+        file_.resize( n > 0 ? (std::size_t)n : 0 );
         if ( n > 0 )
-            in.read( reinterpret_cast<char*>( m_file.data() ), n );
-        m_pos = 0;
-        m_eof = false;
-        m_isOpen = true;
-        m_filename = filename;
+            in.read( reinterpret_cast<char*>( file_.data() ), n );
+        pos_ = 0;
+        eof_ = false;
+        isOpen_ = true;
+        filename_ = filename;
         LOG(Logger::Level::INFO) << "Opened JPEG image: \'" + filename + "\'" << std::endl;
         return true;
     }
 
     void JPEGDecoder::openMemory( const UInt8* data, std::size_t size, const std::string& name )
     {
-        m_file.assign( data, data + size );
-        m_pos = 0;
-        m_eof = false;
-        m_isOpen = true;
-        m_filename = name;
+        file_.assign( data, data + size );
+        pos_ = 0;
+        eof_ = false;
+        isOpen_ = true;
+        filename_ = name;
     }
 
     void JPEGDecoder::close()
     {
-        m_isOpen = false;
-        LOG(Logger::Level::INFO) << "Closed image file: \'" + m_filename + "\'" << std::endl;
+        isOpen_ = false;
+        LOG(Logger::Level::INFO) << "Closed image file: \'" + filename_ + "\'" << std::endl;
     }
 
     // ---- byte cursor ---------------------------------------------------------------------
     bool JPEGDecoder::readByte( UInt8& b )
     {
-        if ( m_eof || m_pos >= m_file.size() )
+        if ( eof_ || pos_ >= file_.size() )
         {
-            m_eof = true;
+            eof_ = true;
             return false;
         }
-        b = m_file[m_pos++];
+        b = file_[pos_++];
         return true;
     }
 
@@ -101,9 +101,9 @@ namespace kpeg
 
     void JPEGDecoder::skip( std::size_t n )
     {
-        if ( m_eof )
+        if ( eof_ )
             return;
-        m_pos = ( m_pos + n > m_file.size() ) ? m_file.size() : m_pos + n;
+        pos_ = ( pos_ + n > file_.size() ) ? file_.size() : pos_ + n;
     }
 
     // ---- marker dispatch -------------------------------------------------------------------
@@ -124,7 +124,7 @@ namespace kpeg
             case JFIF_DHT:  LOG(Logger::Level::INFO) << "Found segment, Define Huffman Table (FFC4)" << std::endl; parseHuffmanTable(); return SUCCESS;
             case JFIF_SOS:  LOG(Logger::Level::INFO) << "Found segment, Start of Scan (FFDA)" << std::endl; parseSOSSegment(); return SUCCESS;
             case JFIF_DRI:
-                if ( m_allowDRI )
+                if ( allowDRI_ )
                 {
                     LOG(Logger::Level::INFO) << "Found segment, Define Restart Interval (FFDD) [extension]" << std::endl;
                     parseDRISegment();
@@ -136,9 +136,9 @@ namespace kpeg
 
     JPEGDecoder::ResultCode JPEGDecoder::decodeImageFile()
     {
-        if ( !m_isOpen )
+        if ( !isOpen_ )
         {
-            LOG(Logger::Level::ERROR) << "Unable scan image file: \'" + m_filename + "\'" << std::endl;
+            LOG(Logger::Level::ERROR) << "Unable scan image file: \'" + filename_ + "\'" << std::endl;
             return ERROR;
         }
         LOG(Logger::Level::INFO) << "Started decoding process..." << std::endl;
@@ -163,7 +163,7 @@ namespace kpeg
 
         if ( status == DECODE_DONE )
         {
-            if ( m_parseOnly )
+            if ( parseOnly_ )
                 return status;
             const ResultCode rc = decodeScanData();
             if ( rc != SUCCESS )
@@ -183,11 +183,11 @@ namespace kpeg
 
     bool JPEGDecoder::dumpRawData()
     {
-        std::size_t extPos = m_filename.find( ".jpg" );
+        std::size_t extPos = filename_.find( ".jpg" );
         if ( extPos == std::string::npos )
-            extPos = m_filename.find( ".jpeg" );
-        const std::string target = m_filename.substr( 0, extPos ) + ".ppm";
-        m_image.dumpRawData( target );
+            extPos = filename_.find( ".jpeg" );
+        const std::string target = filename_.substr( 0, extPos ) + ".ppm";
+        image_.dumpRawData( target );
         return true;
     }
 
@@ -199,7 +199,7 @@ namespace kpeg
         skip( 5 );         // "JFIF\0"
         readByte( major );
         readByte( minor );
-        m_image.setJPEGVersion( std::to_string( major ) + "." + std::to_string( minor >> 4 ) + std::to_string( minor & 0x0F ) );
+        image_.setJPEGVersion( std::to_string( major ) + "." + std::to_string( minor >> 4 ) + std::to_string( minor & 0x0F ) );
         readByte( b );     // density unit
         (void)readBE16();  // x density
         (void)readBE16();  // y density
@@ -218,12 +218,12 @@ namespace kpeg
             readByte( b );
             if ( b == JFIF_BYTE_FF )
             {
-                LOG(Logger::Level::ERROR) << "Unexpected start of marker at offest: " << m_pos << std::endl;
+                LOG(Logger::Level::ERROR) << "Unexpected start of marker at offest: " << pos_ << std::endl;
                 return;  // gives up mid-segment without storing the comment
             }
             comment.push_back( (char)b );
         }
-        m_image.setComment( comment );
+        image_.setComment( comment );
     }
 
     void JPEGDecoder::parseQuantizationTable()
@@ -235,20 +235,20 @@ namespace kpeg
             UInt8 pqtq = 0, q = 0;
             readByte( pqtq );
             const std::size_t id = pqtq & 0x0F;
-            m_QTables.push_back( {} );
-            if ( id >= m_QTables.size() )
+            QTables_.push_back( {} );
+            if ( id >= QTables_.size() )
             {
                 // the reference indexes past the vector here (undefined behaviour)
-                LOG(Logger::Level::ERROR) << "Quantization table id " << id << " before table " << m_QTables.size() - 1
+                LOG(Logger::Level::ERROR) << "Quantization table id " << id << " before table " << QTables_.size() - 1
                                           << ": outside the supported layout" << std::endl;
-                m_tableBroken = true;
+                tableBroken_ = true;
                 for ( int i = 0; i < 64; ++i ) readByte( q );
                 continue;
             }
             for ( int i = 0; i < 64; ++i )
             {
                 readByte( q );
-                m_QTables[id].push_back( (UInt16)q );
+                QTables_[id].push_back( (UInt16)q );
             }
         }
     }
@@ -275,15 +275,15 @@ namespace kpeg
             LOG(Logger::Level::INFO) << "Chroma subsampling not yet supported!" << std::endl;
             return TERMINATE;
         }
-        m_image.setDimensions( w, h );
+        image_.setDimensions( w, h );
         return SUCCESS;
     }
 
     void JPEGDecoder::parseHuffmanTable()
     {
         const UInt16 len = readBE16();
-        const std::size_t segmentEnd = m_pos + len - 2;
-        while ( !m_eof && m_pos < segmentEnd )
+        const std::size_t segmentEnd = pos_ + len - 2;
+        while ( !eof_ && pos_ < segmentEnd )
         {
             UInt8 info = 0, c = 0;
             readByte( info );
@@ -291,10 +291,10 @@ namespace kpeg
             if ( id > 1 )
             {
                 LOG(Logger::Level::ERROR) << "Huffman table id " << id << " is outside the supported layout" << std::endl;
-                m_tableBroken = true;
+                tableBroken_ = true;
                 return;
             }
-            HuffmanTable& t = m_huffmanTable[cls][id];
+            HuffmanTable& t = huffmanTable_[cls][id];
             int total = 0;
             for ( int i = 0; i < 16; ++i )
             {
@@ -311,19 +311,19 @@ namespace kpeg
                     ++li;
                 if ( li == 16 )
                 {
-                    m_tableBroken = true;  // redefinition of a table: the reference keeps appending
+                    tableBroken_ = true;  // redefinition of a table: the reference keeps appending
                     break;
                 }
                 t[li].second.push_back( c );
             }
-            m_huffmanTree[cls][id].constructHuffmanTree( t );
+            huffmanTree_[cls][id].constructHuffmanTree( t );
         }
     }
 
     void JPEGDecoder::parseDRISegment()
     {
         (void)readBE16();
-        m_restartInterval = readBE16();
+        restartInterval_ = readBE16();
     }
 
     void JPEGDecoder::parseSOSSegment()
@@ -340,7 +340,7 @@ namespace kpeg
             (void)readBE16();  // component id + table selectors: ignored (tables are hard-wired)
         for ( int i = 0; i < 3; ++i )
             readByte( b );
-        m_sosCount++;
+        sosCount_++;
         scanImageData();
     }
 
@@ -348,7 +348,7 @@ namespace kpeg
     void JPEGDecoder::scanImageData()
     {
         UInt8 b = 0;
-        m_scan.reserve( m_scan.size() + ( m_file.size() - m_pos ) );
+        scan_.reserve( scan_.size() + ( file_.size() - pos_ ) );
         while ( readByte( b ) )
         {
             if ( b == JFIF_BYTE_FF )
@@ -360,30 +360,30 @@ namespace kpeg
                     LOG(Logger::Level::INFO) << "Found segment, End of Image (FFD9)" << std::endl;
                     return;
                 }
-                m_scan.push_back( prev );
+                scan_.push_back( prev );
             }
-            m_scan.push_back( b );
+            scan_.push_back( b );
         }
     }
 
     // ---- the seam ------------------------------------------------------------------------------
     bool JPEGDecoder::frameInfo( kpeg_frame* f ) const
     {
-        if ( !f || m_tableBroken || m_QTables.size() < 2 || m_QTables[0].size() < 64 || m_QTables[1].size() < 64 )
+        if ( !f || tableBroken_ || QTables_.size() < 2 || QTables_[0].size() < 64 || QTables_[1].size() < 64 )
             return false;
         std::memset( f, 0, sizeof( *f ) );
-        f->width = m_image.getWidth();
-        f->height = m_image.getHeight();
+        f->width = image_.getWidth();
+        f->height = image_.getHeight();
         for ( int t = 0; t < 2; ++t )
             for ( int k = 0; k < 64; ++k )
-                f->qt[t][k] = m_QTables[t][k];  // first 64 entries: what MCU.cpp:110-112 reads
+                f->qt[t][k] = QTables_[t][k];  // first 64 entries: what MCU.cpp:110-112 reads
         for ( int cls = 0; cls < 2; ++cls )
             for ( int id = 0; id < 2; ++id )
             {
                 int k = 0;
                 for ( int i = 0; i < 16; ++i )
                 {
-                    const auto& e = m_huffmanTable[cls][id][i];
+                    const auto& e = huffmanTable_[cls][id][i];
                     if ( e.first < 0 || e.first > 255 || (int)e.second.size() != e.first || k + e.first > 256 )
                         return false;
                     f->dht[cls][id].counts[i] = (UInt8)e.first;
@@ -393,20 +393,20 @@ namespace kpeg
                 if ( k == 0 )
                     return false;
             }
-        f->restart_interval = m_restartInterval;
+        f->restart_interval = restartInterval_;
         return true;
     }
 
     JPEGDecoder::ResultCode JPEGDecoder::decodeScanData()
     {
-        if ( m_scan.empty() )
+        if ( scan_.empty() )
         {
             LOG(Logger::Level::ERROR) << " [ FATAL ] Invalid image scan data" << std::endl;
             return SUCCESS;  // the reference logs and still reports DECODE_DONE with an empty image
         }
         kpeg_frame f;
-        const unsigned w = m_image.getWidth(), h = m_image.getHeight();
-        if ( m_sosCount != 1 || !frameInfo( &f ) || w == 0 || h == 0 || ( w & 7 ) || ( h & 7 ) )
+        const unsigned w = image_.getWidth(), h = image_.getHeight();
+        if ( sosCount_ != 1 || !frameInfo( &f ) || w == 0 || h == 0 || ( w & 7 ) || ( h & 7 ) )
         {
             LOG(Logger::Level::ERROR) << "[ FATAL ] Stream is outside what libKPEG decodes without undefined behaviour "
                                          "(two quantisation tables id 0,1; four Huffman tables id 0/1; one scan; "
@@ -421,13 +421,13 @@ namespace kpeg
             return ERROR;
         }
         std::vector<UInt8> rgb( (std::size_t)w * h * 3 );
-        const int rc = kpeg_hip_decode_scan( ctx, &f, m_scan.data(), m_scan.size(), rgb.data() );
+        const int rc = kpeg_hip_decode_scan( ctx, &f, scan_.data(), scan_.size(), rgb.data() );
         if ( rc != KPEG_HIP_OK )
         {
             LOG(Logger::Level::ERROR) << "[ FATAL ] GPU decode failed: " << kpeg_hip_strerror( rc ) << ": " << kpeg_hip_last_error( ctx ) << std::endl;
             return ERROR;
         }
-        m_image.adoptRGB8( std::move( rgb ) );
+        image_.adoptRGB8( std::move( rgb ) );
         return SUCCESS;
     }
 }

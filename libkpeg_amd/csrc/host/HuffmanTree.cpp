@@ -65,14 +65,14 @@ namespace kpeg
         inOrder( node->rChild );
     }
 
-    HuffmanTree::HuffmanTree() : m_root{ nullptr } {}
+    HuffmanTree::HuffmanTree() : root_{ nullptr } {}
 
     HuffmanTree::HuffmanTree( const HuffmanTable& htable ) { constructHuffmanTree( htable ); }
 
     void HuffmanTree::constructHuffmanTree( const HuffmanTable& htable )
     {
-        m_root = createRootNode( 0x0000 );
-        std::vector<NodePtr> open{ m_root };  // unassigned nodes of the current depth, left to right
+        root_ = createRootNode( 0x0000 );
+        std::vector<NodePtr> open{ root_ };  // unassigned nodes of the current depth, left to right
         for ( int len = 1; len <= 16; ++len )
         {
             std::vector<NodePtr> next;
@@ -97,7 +97,7 @@ namespace kpeg
         }
     }
 
-    const NodePtr HuffmanTree::getTree() const { return m_root; }
+    const NodePtr HuffmanTree::getTree() const { return root_; }
 
     const std::string HuffmanTree::contains( const std::string& huffCode )
     {
@@ -106,7 +106,7 @@ namespace kpeg
             LOG(Logger::Level::ERROR) << "[ FATAL ] Invalid huffman code, possibly corrupt JFIF data stream!" << std::endl;
             return "";
         }
-        NodePtr n = m_root;
+        NodePtr n = root_;
         for ( std::size_t i = 0; i < huffCode.size() && n != nullptr; ++i )
         {
             n = huffCode[i] == '0' ? n->lChild : n->rChild;

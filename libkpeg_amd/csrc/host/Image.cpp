@@ -9,8 +9,8 @@
 namespace kpeg
 {
     Image::Image() :
-        m_filename{ "" }, m_pixelPtr{ nullptr }, m_flPixelPtr{ nullptr }, m_JPEGversion{ "" }, m_comment{ "" },
-        m_width{ 0 }, m_height{ 0 }
+        filename_{ "" }, pixelPtr_{ nullptr }, flPixelPtr_{ nullptr }, JPEGversion_{ "" }, comment_{ "" },
+        width_{ 0 }, height_{ 0 }
     {
     }
 
@@ -18,40 +18,40 @@ namespace kpeg
     // columns/rows beyond the image size are cropped (reference src/Image.cpp:26-84).
     void Image::createImageFromMCUs( const std::vector<MCU>& MCUVector )
     {
-        const std::size_t tw = ( m_width + 7 ) / 8, th = ( m_height + 7 ) / 8;
+        const std::size_t tw = ( width_ + 7 ) / 8, th = ( height_ + 7 ) / 8;
         if ( MCUVector.size() < tw * th )
         {
             LOG(Logger::Level::ERROR) << "createImageFromMCUs: " << MCUVector.size() << " MCUs given, " << tw * th << " needed" << std::endl;
             return;
         }
-        std::vector<UInt8> rgb( m_width * m_height * 3 );
+        std::vector<UInt8> rgb( width_ * height_ * 3 );
         for ( std::size_t tr = 0; tr < th; ++tr )
             for ( std::size_t tc = 0; tc < tw; ++tc )
             {
                 const CompMatrices& b = MCUVector[tr * tw + tc].getAllMatrices();
-                for ( std::size_t v = 0; v < 8 && tr * 8 + v < m_height; ++v )
-                    for ( std::size_t u = 0; u < 8 && tc * 8 + u < m_width; ++u )
+                for ( std::size_t v = 0; v < 8 && tr * 8 + v < height_; ++v )
+                    for ( std::size_t u = 0; u < 8 && tc * 8 + u < width_; ++u )
                         for ( int c = 0; c < 3; ++c )
-                            rgb[( ( tr * 8 + v ) * m_width + tc * 8 + u ) * 3 + c] = (UInt8)b[c][v][u];
+                            rgb[( ( tr * 8 + v ) * width_ + tc * 8 + u ) * 3 + c] = (UInt8)b[c][v][u];
             }
         adoptRGB8( std::move( rgb ) );
     }
 
     void Image::adoptRGB8( std::vector<UInt8>&& rgb )
     {
-        m_rgb8 = std::move( rgb );
-        m_pixelPtr.reset();
+        rgb8_ = std::move( rgb );
+        pixelPtr_.reset();
     }
 
-    const std::vector<UInt8>& Image::getRGB8() const { return m_rgb8; }
+    const std::vector<UInt8>& Image::getRGB8() const { return rgb8_; }
 
     PixelPtr Image::getPixelPtr()
     {
-        if ( !m_pixelPtr && m_rgb8.size() == m_width * m_height * 3 && !m_rgb8.empty() )
+        if ( !pixelPtr_ && rgb8_.size() == width_ * height_ * 3 && !rgb8_.empty() )
         {
-            m_pixelPtr = std::make_shared<std::vector<std::vector<Pixel>>>( m_height, std::vector<Pixel>( m_width ) );
-            const UInt8* p = m_rgb8.data();
-            for ( auto& row : *m_pixelPtr )
+            pixelPtr_ = std::make_shared<std::vector<std::vector<Pixel>>>( height_, std::vector<Pixel>( width_ ) );
+            const UInt8* p = rgb8_.data();
+            for ( auto& row : *pixelPtr_ )
                 for ( auto& px : row )
                 {
                     px.comp[0] = p[0];
@@ -60,17 +60,17 @@ namespace kpeg
                     p += 3;
                 }
         }
-        return m_pixelPtr;
+        return pixelPtr_;
     }
 
-    FPixelPtr Image::getFlPixelPtr() { return m_flPixelPtr; }
-    const unsigned Image::getWidth() const { return (unsigned)m_width; }
-    const unsigned Image::getHeight() const { return (unsigned)m_height; }
+    FPixelPtr Image::getFlPixelPtr() { return flPixelPtr_; }
+    const unsigned Image::getWidth() const { return (unsigned)width_; }
+    const unsigned Image::getHeight() const { return (unsigned)height_; }
 
     const bool Image::dumpRawData( const std::string& filename )
     {
-        const bool haveRGB = !m_rgb8.empty() && m_rgb8.size() == m_width * m_height * 3;
-        if ( !haveRGB && m_pixelPtr == nullptr )
+        const bool haveRGB = !rgb8_.empty() && rgb8_.size() == width_ * height_ * 3;
+        if ( !haveRGB && pixelPtr_ == nullptr )
         {
             LOG(Logger::Level::ERROR) << "Unable to create dump file \'" + filename + "\', Invalid pixel pointer" << std::endl;
             return false;
@@ -83,12 +83,12 @@ namespace kpeg
         }
         // header bytes are part of the bit-exact output (reference src/Image.cpp:124-127)
         std::fprintf( f, "P6\n# PPM dump created using libKPEG: https://github.com/TheIllusionistMirage/libKPEG\n%zu %zu\n255\n",
-                      m_width, m_height );
+                      width_, height_ );
         bool ok = true;
         if ( haveRGB )
-            ok = std::fwrite( m_rgb8.data(), 1, m_rgb8.size(), f ) == m_rgb8.size();
+            ok = std::fwrite( rgb8_.data(), 1, rgb8_.size(), f ) == rgb8_.size();
         else
-            for ( auto&& row : *m_pixelPtr )
+            for ( auto&& row : *pixelPtr_ )
                 for ( auto&& px : row )
                 {
                     const UInt8 b[3] = { (UInt8)px.comp[0], (UInt8)px.comp[1], (UInt8)px.comp[2] };
@@ -134,9 +134,9 @@ namespace kpeg
         in.get();  // single whitespace before the raster
         if ( !in.good() || width == 0 || height == 0 )
             return false;
-        m_width = width;
-        m_height = height;
-        m_flPixelPtr = std::make_shared<std::vector<std::vector<FPixel>>>( height, std::vector<FPixel>( width ) );
+        width_ = width;
+        height_ = height;
+        flPixelPtr_ = std::make_shared<std::vector<std::vector<FPixel>>>( height, std::vector<FPixel>( width ) );
         std::vector<UInt8> row( (std::size_t)width * 3 );
         for ( unsigned y = 0; y < height; ++y )
         {
@@ -144,19 +144,19 @@ namespace kpeg
             if ( (std::size_t)in.gcount() != row.size() )
                 return false;
             for ( unsigned x = 0; x < width; ++x )
-                ( *m_flPixelPtr )[y][x] = FPixel( row[x * 3], row[x * 3 + 1], row[x * 3 + 2] );
+                ( *flPixelPtr_ )[y][x] = FPixel( row[x * 3], row[x * 3 + 1], row[x * 3 + 2] );
         }
-        m_filename = filename;
+        filename_ = filename;
         return true;
     }
 
-    void Image::setImageFilename( const std::string& filename ) { m_filename = filename; }
-    void Image::setJPEGVersion( const std::string& version ) { m_JPEGversion = version; }
-    void Image::setComment( const std::string& comment ) { m_comment = comment; }
+    void Image::setImageFilename( const std::string& filename ) { filename_ = filename; }
+    void Image::setJPEGVersion( const std::string& version ) { JPEGversion_ = version; }
+    void Image::setComment( const std::string& comment ) { comment_ = comment; }
     void Image::setDimensions( const std::size_t width, const std::size_t height )
     {
-        m_width = width;
-        m_height = height;
+        width_ = width;
+        height_ = height;
     }
 
     // ---- bit-string helpers (reference src/Image.cpp:258-320) ------------------------------

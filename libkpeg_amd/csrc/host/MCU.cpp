@@ -16,13 +16,13 @@
 
 namespace kpeg
 {
-    int MCU::m_MCUCount = 0;
-    std::vector<std::vector<UInt16>> MCU::m_QTables = {};
+    int MCU::MCUCount_ = 0;
+    std::vector<std::vector<UInt16>> MCU::QTables_ = {};
     int MCU::DCDiff[3] = { 0, 0, 0 };
 
     MCU::MCU()
     {
-        for ( auto& c : m_8x8block )
+        for ( auto& c : blocks_ )
             for ( auto& r : c )
                 r.fill( 0 );
     }
@@ -34,8 +34,8 @@ namespace kpeg
 
     void MCU::constructMCU( const std::array<std::vector<int>, 3>& compRLE, const std::vector<std::vector<UInt16>>& QTables )
     {
-        m_QTables = QTables;
-        m_MCUCount++;
+        QTables_ = QTables;
+        MCUCount_++;
         if ( QTables.size() < 2 || QTables[0].size() < 64 || QTables[1].size() < 64 )
             throw std::runtime_error( "kpeg::MCU: two 64-entry quantisation tables are required" );
 
@@ -88,12 +88,12 @@ namespace kpeg
         for ( int r = 0; r < 8; ++r )
             for ( int x = 0; x < 8; ++x )
                 for ( int c = 0; c < 3; ++c )
-                    m.m_8x8block[c][r][x] = rgb[r * pitch + x * 3 + c];
+                    m.blocks_[c][r][x] = rgb[r * pitch + x * 3 + c];
         return m;
     }
 
-    const CompMatrices& MCU::getAllMatrices() const { return m_8x8block; }
-    const Matrix8x8 MCU::getYMatrix() const { return m_8x8block[0]; }
-    const Matrix8x8 MCU::getCbMatrix() const { return m_8x8block[1]; }
-    const Matrix8x8 MCU::getCrMatrix() const { return m_8x8block[2]; }
+    const CompMatrices& MCU::getAllMatrices() const { return blocks_; }
+    const Matrix8x8 MCU::getYMatrix() const { return blocks_[0]; }
+    const Matrix8x8 MCU::getCbMatrix() const { return blocks_[1]; }
+    const Matrix8x8 MCU::getCrMatrix() const { return blocks_[2]; }
 }
