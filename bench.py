@@ -275,8 +275,31 @@ def main():
     tm = {k: v / nprof for k, v in acc.items()}
 
     # ---- SURVEY 8(d) side figures (single GPU, default workload): device-copy ceiling and the dense stress input
-    copy_gbs = stress = None
+    copy_gbs = stress = two_streams = None
     if args.side_figures and world == 1 and not args.idct_only and (W, H) == (W8K, H8K):
+        # successive images alternating between two contexts/streams: one image's entropy kernels (latency-bound)
+        # overlap the previous image's IDCT (instruction-bound).  The headline stays the one-stream number.
+        ctx2 = K.Context(local_rank)
+        st2 = torch.cuda.Stream()
+        ctx2.set_stream(st2.cuda_stream)
+        d_rgb2 = torch.empty_like(d_rgb)
+        pair = [(ctx, d_rgb), (ctx2, d_rgb2)]
+        def step2(i):
+            c, o = pair[i & 1]
+            c.decode_stripe_dev(frame, d_scan.data_ptr(), d_scan.numel(), first_row, rows, o.data_ptr())
+        for i in range(4):
+            step2(i)
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        for i in range(40):
+            step2(i)
+        torch.cuda.synchronize()
+        pms = (time.perf_counter() - p0) / 40 * 1e3
+        ctx.sync()
+        ctx2.sync()
+        two_streams = {"ms_per_image": round(pms, 4), "value": round(W * H / (pms * 1e-3) / 1e6, 2), "unit": "Mpixels/s",
+                       "what": "the same image decoded back to back, alternating between two contexts on two HIP streams"}
+        del d_rgb2
         a = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
         b = torch.empty_like(a)
         for _ in range(3):
@@ -381,6 +404,8 @@ def main():
                 "K0_unstuff": gbs(2 * S, tm.get("unstuff_ms")), "K1_sync": gbs(S, tm.get("huff_sync_ms")),
                 "K2_write": gbs(S + 6 * px, tm.get("huff_write_ms")), "K4_idct_colour": gbs(9 * px, tm.get("idct_ms")),
                 "end_to_end_fused_minimum": gbs((S + 3 * px) * world, ms_per_step)}
+        if two_streams:
+            out["two_streams"] = two_streams
         if stress:
             out["stress"] = stress
         if gather:
