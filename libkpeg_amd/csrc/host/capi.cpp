@@ -29,10 +29,10 @@ extern "C" int kpeg_host_parse( const uint8_t* file, size_t size, unsigned flags
             return -1;
         const std::vector<kpeg::UInt8>& s = dec.scanData();
         *scan_len = s.size();
-        if ( scan && s.size() <= scan_cap )
-            std::memcpy( scan, s.data(), s.size() );
-        else if ( scan )
+        if ( scan && s.size() > scan_cap )
             return -1;
+        if ( scan && !s.empty() )
+            std::memcpy( scan, s.data(), s.size() );
         return rc;
     }
     catch ( ... )
