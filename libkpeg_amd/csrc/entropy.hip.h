@@ -1246,6 +1246,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         const uint32_t gbase = seg_mcu0 * 3;
         uint32_t gb = gbase + (b ? b - 1 : 0);          // block in progress
         if (k != 0 && b == 0) err |= 64;                // inside a block before the segment's first one began
+        // a corrupt stream can count more blocks than the segment has: nothing is written for those
+        constexpr uint32_t F_INSIDE = 1u << 11;         // the block in progress lies inside the segment
+        if (b >= 1 && b - 1 < blk_limit) F |= F_INSIDE;
 #if KPEG_ABLATE_W == 2
         if (a.nmcu == 0)
 #endif
@@ -1273,13 +1276,13 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                 pd2 = n;
                 gb = gbase + b;
                 b++;
-                F = (F & (F_OVER | F_HEAD | F_HEAD_NONCORNER)) | F_STARTED | ((e >> 25) & 1u);   // E_KEEP -> F_KEEP
+                F = (F & (F_OVER | F_HEAD | F_HEAD_NONCORNER)) | F_STARTED | F_INSIDE | ((e >> 25) & 1u);   // E_KEEP -> F_KEEP; b < blk_limit here
             }
             const int v = isdc ? n : ext;
             // zig-zag position: DC 0; AC kraw - 1, which is >= 64 for an EOB, "no such code" and a run past the end
             const uint32_t posraw = kraw - 1, pos = posraw & 63;
             if (!isdc && !(e & E_ZERO) && kraw > 64) F |= F_OVER;
-            if (isdc || ((F & F_KEEP) && posraw < 64)) {
+            if ((F & F_INSIDE) && (isdc || ((F & F_KEEP) && posraw < 64))) {
 #if KPEG_ABLATE_W != 1 && KPEG_ABLATE_W != 3
                 a.coef[((size_t)gb << 6) | T.zz[pos]] = (int16_t)v;
 #endif
@@ -1292,7 +1295,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             }
             if (adv && !isdc) {
                 // the block is complete
-                if (F & F_STARTED) {
+                if (!(F & F_INSIDE)) {
+                    // a block the segment does not have (corrupt stream): no bound to write
+                } else if (F & F_STARTED) {
                     // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
                     const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
                     // even mantissa, rounded up; lowest bit = chroma samples may leave the f32 colour range (Asum >= 249)
@@ -1310,7 +1315,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                     hgb = gb;
                     hchroma = (int)tdc;
                 }
-                F &= F_OVER | F_HEAD | F_HEAD_NONCORNER;
+                F &= F_OVER | F_HEAD | F_HEAD_NONCORNER | F_INSIDE;
                 Asum = 0.0f;
                 nnz = 0;
             }
@@ -1322,12 +1327,12 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         hcorner = !(F & F_HEAD_NONCORNER);
         tail_gb = gb;
         tail_chroma = tb >= 2 * LUT_BYTES ? 1 : 0;
-        if (k != 0)
+        if (k != 0 && (F & F_INSIDE))
             share = make_int4(__float_as_int(Asum), nnz, SH_OPEN | ((F & F_NONCORNER) ? 0 : SH_CORNER) | ((F & F_STARTED) ? SH_STARTED : 0), 0);
         // the last sub-sequence of a segment must have produced the segment's last block, all of it
         if (g.li + 1 == a.sub_base[g.seg + 1] - first) {
             if (b < blk_limit) err |= 128;
-            if (k != 0) err |= 64;
+            if (k != 0 && (F & F_INSIDE)) err |= 64;   // (bits after the segment's last block are ignored, as the reference ignores them)
         }
     }
     __syncthreads();   // every lane has read its s_pre

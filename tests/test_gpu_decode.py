@@ -85,6 +85,21 @@ def test_random_sweep_against_the_oracle(ctx):
         assert np.array_equal(got, want), (case, w, h, q, sigma, mode, seed, interval)
 
 
+def test_more_entropy_data_than_the_frame_needs(ctx):
+    """SOF0 says 64x32 but the scan holds the blocks of 64x64: the reference decodes (W*H)/64 MCUs and ignores the
+    rest of the bits (Decoder.cpp:670); so does K2 -- and it must not write the surplus blocks anywhere."""
+    data = bytearray(T.synth_jpeg(64, 64, seed=31))
+    i = data.find(b"\xff\xc0")
+    assert i > 0 and data[i + 5:i + 7] == bytes([0, 64])
+    data[i + 5:i + 7] = bytes([0, 32])
+    data = bytes(data)
+    st, want = T.oracle_decode(data)
+    assert st == T.DECODE_DONE and want.shape == (32, 64, 3)
+    p = T.oracle_parse(data)
+    got = ctx.decode_scan(T.make_frame(p), p.scan)
+    assert np.array_equal(got, want)
+
+
 def test_flat_image(ctx):
     """A constant image is a periodic bit string (14 bits per MCU: DC diff 0 + EOB, three times)."""
     rgb = np.empty((1024, 2048, 3), np.uint8)
