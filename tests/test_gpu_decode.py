@@ -100,6 +100,41 @@ def test_more_entropy_data_than_the_frame_needs(ctx):
     assert np.array_equal(got, want)
 
 
+def test_corrupted_scans_fail_cleanly(ctx):
+    """120 seeded corruptions of an entropy-coded segment (bit flips, byte runs overwritten, truncations, surplus
+    bytes): every decode either succeeds or reports KPEG_HIP_E_STREAM -- no fault, no hang -- and the context
+    decodes the clean stream correctly afterwards."""
+    import libkpeg_amd as K
+    data = T.synth_jpeg(256, 128, seed=77, sigma=12.0)
+    st, want = T.oracle_decode(data)
+    p = T.oracle_parse(data)
+    frame = T.make_frame(p)
+    clean = np.frombuffer(p.scan, dtype=np.uint8)
+    rng = np.random.default_rng(99)
+    failed = 0
+    for case in range(120):
+        s = clean.copy()
+        kind = case % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                s[int(rng.integers(0, s.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        elif kind == 1:
+            a = int(rng.integers(0, s.size - 40))
+            s[a:a + int(rng.integers(1, 40))] = rng.integers(0, 256, dtype=np.uint8)
+        elif kind == 2:
+            s = s[:int(rng.integers(1, s.size))].copy()
+        else:
+            s = np.concatenate([s, rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8)])
+        try:
+            out = ctx.decode_scan(frame, s)
+            assert out.shape == want.shape
+        except K.KpegError as e:
+            assert e.code == -4, e   # KPEG_HIP_E_STREAM
+            failed += 1
+    assert failed > 10   # most truncations must be detected
+    assert np.array_equal(ctx.decode_scan(frame, p.scan), want)
+
+
 def test_flat_image(ctx):
     """A constant image is a periodic bit string (14 bits per MCU: DC diff 0 + EOB, three times)."""
     rgb = np.empty((1024, 2048, 3), np.uint8)
