@@ -8,8 +8,9 @@
 // A baseline scan without restart markers is one serial bit string, so the decode is the
 // two-pass "self-synchronising sub-sequence" scheme:
 //   K0  unstuff   byte-parallel removal of the 00 after FF (reference rule incl. its tail
-//                 rule) and, with DRI, of the RSTn markers; prefix-sum compaction.  Output
-//                 is the bit string as big-endian 32-bit words + restart-segment offsets.
+//                 rule) and, with DRI, of the RSTn markers; compaction by decoupled look-back,
+//                 one launch.  Output is the bit string as big-endian 32-bit words +
+//                 restart-segment offsets (the images of a fused batch are such segments).
 //   K1  sync      one item per sub-sequence of SUBSEQ_BITS bits: decode from a guessed
 //                 codeword boundary, then rounds of "re-decode from my predecessor's exit
 //                 state" for exactly the items whose predecessor moved (a compacted work
@@ -20,13 +21,17 @@
 //                 the predecessor's real exit state and only a workgroup that guessed wrong
 //                 decodes again.  The first sub-sequence of every restart segment starts from
 //                 a known state.  Each run also counts the blocks it starts and sums their DC
-//                 differences.  Pass 0 clears the coefficient buffer in the background.
-//       scan      exclusive prefix sum of (blocks, dc[3]) over sub-sequences: absolute
-//                 block index and DC predictors at every sub-sequence entry.
-//   K2  write     one lane per sub-sequence decodes again from its true entry state and
-//                 scatters the non-zero coefficients into the cleared buffer (natural order,
-//                 absolute DC, quirk Q1 applied) -- the layout K4 reads -- plus K4's
-//                 per-block error bound.
+//                 differences.  Pass 0 clears the coefficient buffer in the background.  The
+//                 third and last launch is chained (every workgroup waits for its predecessor's
+//                 published state) if pass 1 still moved something -- no stream is given up --
+//                 and in any case runs the
+//       scan      exclusive prefix sum of (blocks, dc[3]) over the workgroups: with K2's local
+//                 scan, absolute block index and DC predictors at every sub-sequence entry.
+//   K2  write     one lane per sub-sequence decodes its own symbols again from its true entry
+//                 state and scatters the non-zero coefficients into the cleared buffer (natural
+//                 order, absolute DC, quirk Q1 applied) -- the layout K4 reads -- plus K4's
+//                 per-block error bound (blocks split over lanes or workgroups are settled by
+//                 the side that holds their end).
 // The decode loops are bound by the instruction count of one symbol step (a wavefront runs
 // ~5 cycles per instruction on its own), so a Huffman table entry is a ready-made 32-bit
 // record (bits used, coefficient advance, flags) and the decoder's state is the LDS address
