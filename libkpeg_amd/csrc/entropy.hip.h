@@ -61,19 +61,29 @@ namespace kpeg_dev {
 #ifndef KPEG_SYNC_WG
 #define KPEG_SYNC_WG 512
 #endif
-constexpr int SUBSEQ_BITS = KPEG_SUBSEQ_BITS;  // bits per sub-sequence (tunable multiple of 32 >= 64; 96 measured best on the 8K workload)
-constexpr int SUBSEQ_WORDS = SUBSEQ_BITS / 32;
+#ifndef KPEG_SUBSEQ_BITS_DENSE
+#define KPEG_SUBSEQ_BITS_DENSE 384
+#endif
+// Bits per sub-sequence: a multiple of 32, >= 64.  K1/K2 exist for two sizes and the host picks per call from
+// the stream's bit rate: 96 (best on the 8K q75 workload, ~1 bit per pixel) and 384 for dense streams (from
+// 4 bits per pixel: they re-synchronise over thousands of bits, and fewer, longer rounds halve K1's time).
+constexpr int SUBSEQ_SPARSE = KPEG_SUBSEQ_BITS, SUBSEQ_DENSE = KPEG_SUBSEQ_BITS_DENSE;
 constexpr int SYNC_WG = KPEG_SYNC_WG;          // threads per workgroup of K1 and K2
 constexpr int SYNC_PASSES = 3;   // sync kernels enqueued per call: pass 0, the verifying pass 1, the chained pass (+ scan of the totals)
 #ifndef KPEG_WARM_BITS
 #define KPEG_WARM_BITS 1024
 #endif
 constexpr int WARM_BITS = KPEG_WARM_BITS;  // a workgroup decodes this much of its predecessor's tail to find its own entry state
-constexpr int WARM = (WARM_BITS + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
-constexpr int OWN = SYNC_WG - WARM;   // sub-sequences per workgroup: with the warm-up ones a thread each
 constexpr int ITEMS = SYNC_WG;
-static_assert(OWN >= WARM && OWN >= 64, "workgroup too small for the warm-up distance");
-static_assert(SUBSEQ_BITS >= 64 && SUBSEQ_BITS % 32 == 0, "a symbol (<= 31 bits) must not jump over a whole sub-sequence");
+// the geometry that follows from the sub-sequence size S, as local constants of the code templated on S
+#define KPEG_GEOMETRY(S)                                                                                                  \
+    constexpr int SUBSEQ_BITS = (S), SUBSEQ_WORDS = (S) / 32;                                                             \
+    constexpr int WARM = (WARM_BITS + (S) - 1) / (S); /* warm-up sub-sequences */                                         \
+    constexpr int OWN = SYNC_WG - WARM; /* sub-sequences per workgroup: with the warm-up ones a thread each */            \
+    static_assert(OWN >= WARM && OWN >= 64, "workgroup too small for the warm-up distance");                              \
+    static_assert((S) >= 64 && (S) % 32 == 0, "a symbol (<= 31 bits) must not jump over a whole sub-sequence");          \
+    (void)SUBSEQ_BITS;                                                                                                    \
+    (void)SUBSEQ_WORDS
 
 constexpr int LUT_BITS = 9;
 constexpr int LUT2_BITS = 16 - LUT_BITS;  // remaining bits of a long code
@@ -224,6 +234,7 @@ struct EntropyLaunch {
     int num_cus;
     int sync_passes;   // 0 = default
     int warm;          // warm-up sub-sequences per workgroup, < 0 = default (test hook: 0 makes every workgroup guess wrong)
+    int subseq = 0;    // sub-sequence size: 0 = chosen from the bit rate, else SUBSEQ_SPARSE or SUBSEQ_DENSE (test hook)
     // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
     // from the known state, DC predictors reset): d_scan / scan_len are unused, restart_interval = MCUs per image
     uint32_t nimg = 0;
@@ -285,7 +296,8 @@ constexpr unsigned long long LB_AGG = 1ull << 62, LB_PFX = 2ull << 62;
 // workgroup of k_unstuff to finish (US_THREADS threads); seg_off[] was written by other workgroups of the
 // same launch, hence the L2 loads.
 __device__ void seg_setup_wg(EntropyMeta* meta, uint32_t* seg_off, uint32_t* sub_base, uint32_t seg_cap, uint32_t nsub_cap, uint8_t* u,
-                             uint32_t n_u, uint32_t nseg, uint32_t expected_segs, uint32_t* status, uint32_t* s /* [US_THREADS] */, uint32_t* carry)
+                             uint32_t n_u, uint32_t nseg, uint32_t expected_segs, uint32_t* status, uint32_t subseq_bits, uint32_t* s /* [US_THREADS] */,
+                             uint32_t* carry)
 {
     const uint32_t t = threadIdx.x;
     if (t == 0) {
@@ -316,7 +328,7 @@ __device__ void seg_setup_wg(EntropyMeta* meta, uint32_t* seg_off, uint32_t* sub
         uint32_t v = 0;
         if (r < nseg) {
             const uint32_t bits = (seg_at(r + 1) - seg_at(r)) * 8;
-            v = (bits + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
+            v = (bits + subseq_bits - 1) / subseq_bits;
             if (v == 0) v = 1;
         }
         s[t] = v;
@@ -353,7 +365,8 @@ struct UnstuffBatch {   // nimg > 0: workgroup g belongs to the image whose [wg_
 };
 __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
                                                         uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
-                                                        uint32_t nsub_cap, uint32_t* status, UnstuffBatch bt, uint32_t expected_segs)
+                                                        uint32_t nsub_cap, uint32_t* status, UnstuffBatch bt, uint32_t expected_segs,
+                                                        uint32_t subseq_bits)
 {
     __shared__ uint32_t s_wave[US_THREADS / 64];
     __shared__ uint32_t s_base[2];
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
             if (t == 0) {
                 meta->n_u = n_u;
                 meta->nseg = 1;
-                uint32_t nsub = (n_u * 8 + SUBSEQ_BITS - 1) / SUBSEQ_BITS;
+                uint32_t nsub = (n_u * 8 + subseq_bits - 1) / subseq_bits;
                 if (nsub == 0) nsub = 1;
                 seg_off[1] = n_u;
                 sub_base[0] = 0;
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
     if (s_last) {
         const unsigned long long tot = __hip_atomic_load(&part[gridDim.x - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t n_u = (uint32_t)(tot & 0xFFFFFFFu), nseg = bt.nimg ? bt.nimg : (uint32_t)((tot >> 28) & 0x7FFFFFFu) + 1;
-        seg_setup_wg(meta, seg_off, sub_base, seg_cap, nsub_cap, u, n_u, nseg, expected_segs, status, s_out, &s_base[0]);
+        seg_setup_wg(meta, seg_off, sub_base, seg_cap, nsub_cap, u, n_u, nseg, expected_segs, status, subseq_bits, s_out, &s_base[0]);
         if (t < 64) meta->k0_slot[t] = 0;
         if (t == 64) meta->k0_top = 0;
     }
@@ -743,9 +756,11 @@ struct SubGeom {
     uint32_t seg, li;      // segment and index inside it
     uint32_t pstart, pend; // bit range of the sub-sequence
 };
+template <int S>
 __device__ __forceinline__ SubGeom sub_geom(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ sub_base,
                                             uint32_t nseg, uint32_t i)
 {
+    KPEG_GEOMETRY(S);
     SubGeom g;
     g.seg = nseg > 1 ? locate_segment(sub_base, nseg, i) : 0;
     g.li = i - sub_base[g.seg];
@@ -802,9 +817,11 @@ __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list,
 // Scan of (nb, dc0, dc1, dc2): workgroup totals -> exclusive prefix, by one workgroup of K1's last
 // launch (SYNC_WG threads; s = SYNC_WG int4 of LDS); also the call's bookkeeping: blocks found, passes
 // used, K0's look-back words cleared for the next call.
+template <int S>
 __device__ void wsum_scan(int4* wsum, EntropyMeta* meta, uint32_t* status, int pass, bool rippling, unsigned long long* part,
                           uint32_t nparts, int4* s, int4* carry)
 {
+    KPEG_GEOMETRY(S);
     const uint32_t t = threadIdx.x;
     for (uint32_t i = t; i < nparts; i += SYNC_WG) part[i] = 0ull;
     const uint32_t nw = (meta->nsub + OWN - 1) / OWN;
@@ -852,8 +869,10 @@ __device__ void wsum_scan(int4* wsum, EntropyMeta* meta, uint32_t* status, int p
 //   the stream needs more than WARM_BITS to re-synchronise.
 // Pass p >= 1: a workgroup whose assumed entry state differs from its predecessor's real exit
 //   state re-decodes from that state and the change ripples on.
+template <int S>
 __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 {
+    KPEG_GEOMETRY(S);
     __shared__ __attribute__((aligned(16))) LdsTables T;
     __shared__ uint64_t s_X[ITEMS + 1];
     __shared__ uint32_t s_geo[ITEMS + 1];   // pend | first-of-its-segment << 31
@@ -871,7 +890,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
     const bool rippling = p >= 2 && a.meta->moved[p - 1] != 0;
     if (a.chained && !rippling) {
-        if (g == 0) wsum_scan(a.wsum, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (g == 0) wsum_scan<S>(a.wsum, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
         return;
     }
     if (i0 >= nsub) return;
@@ -883,7 +902,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s_n[0] = atomicAdd(&a.meta->ticket, 1u) == (nsub + OWN - 1) / OWN - 1 ? 1u : 0u;
         }
         __syncthreads();
-        if (s_n[0]) wsum_scan(a.wsum, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (s_n[0]) wsum_scan<S>(a.wsum, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
     };
     const uint64_t* Xb_prev = a.Xb + (size_t)((p & 1) ^ 1) * a.nwg_cap;
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
@@ -926,7 +945,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     const uint32_t wu = p == 0 ? min(a.warm, i0) : 0u;
     const uint32_t ibase = i0 - wu, nit = wu + nown;
     // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
-    const uint32_t w0 = sub_geom(a.seg_off, a.sub_base, nseg, ibase).pstart >> 5;
+    const uint32_t w0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase).pstart >> 5;
     {
         const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
@@ -935,7 +954,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     if (t == 0 && p == 0) {
         // item 0 starts from its guess (matters as this workgroup's assumption only without warm-up)
         DecState s0;
-        s0.p = sub_geom(a.seg_off, a.sub_base, nseg, ibase).pstart;
+        s0.p = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase).pstart;
         s0.c = s0.k = s0.q = 0;
         s_X[0] = pack_state(s0);
     }
@@ -950,7 +969,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             const uint32_t j = jb + t;
             bool want = false;
             if (j < nit) {
-                const SubGeom geo = sub_geom(a.seg_off, a.sub_base, nseg, ibase + j);
+                const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase + j);
                 s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
                 DecState s;
                 s.p = geo.pstart;
@@ -970,7 +989,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         }
     } else {
         for (uint32_t j = t; j < nit; j += SYNC_WG) {
-            const SubGeom geo = sub_geom(a.seg_off, a.sub_base, nseg, ibase + j);
+            const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase + j);
             s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
             s_X[j + 1] = a.X[i0 + j];
             s_cnt[j] = a.cnt[i0 + j];
@@ -1127,8 +1146,10 @@ struct WriteArgs {
 // A block split over two workgroups: both sides swap their sum into an exchange slot, and the side that
 // finds the other's sum there settles the bound.  Bounds are preset to +inf (K4's exact path), so a
 // block nobody settles (corrupt stream) is still decoded correctly.
+template <int S>
 __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
 {
+    KPEG_GEOMETRY(S);
     __shared__ __attribute__((aligned(16))) LdsTables T;
     __shared__ int4 s_pre[SYNC_WG];   // first the scan of cnt, then every lane's share of the block open at its exit
     __shared__ int4 s_wred[SYNC_WG / 64];
@@ -1141,7 +1162,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     const uint32_t i = i0 + threadIdx.x;
     const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
     const uint32_t nseg = a.meta->nseg;
-    const SubGeom g0 = sub_geom(a.seg_off, a.sub_base, nseg, i0);
+    const SubGeom g0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, i0);
     const uint32_t w0 = g0.pstart >> 5;
     {
         const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
@@ -1199,7 +1220,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
     int4 pre = make_int4(0, 0, 0, 0);
     if (valid) {
-        const SubGeom g = sub_geom(a.seg_off, a.sub_base, nseg, i);
+        const SubGeom g = sub_geom<S>(a.seg_off, a.sub_base, nseg, i);
         DecState s;
         if (g.li == 0) {
             s.p = g.pstart;
@@ -1413,9 +1434,11 @@ static int ent_grow(void** p, size_t* cap, size_t need, hipStream_t stream, std:
 }
 
 // ev: kpeg_hip_ctx::ev (EV_UNSTUFF=1, EV_SYNC=2, EV_SCAN=3, EV_WRITE=4, EV_DC=5) or null
-static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, const EntropyLaunch& L, hipEvent_t* ev, bool* ev_rec,
-                                 std::string* err)
+template <int SB>
+static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs, const EntropyLaunch& L, hipEvent_t* ev, bool* ev_rec,
+                                   std::string* err)
 {
+    KPEG_GEOMETRY(SB);
 #define ENT_HIP(expr)                                                      \
     do {                                                                   \
         hipError_t _e = (expr);                                            \
@@ -1481,7 +1504,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     if (!S->part_clean) ENT_HIP(hipMemsetAsync(S->d_part, 0, S->part_cap, L.stream));
     S->part_clean = false;
     hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, markers, (unsigned long long*)S->d_part,
-                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt, nseg_expected);
+                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt, nseg_expected, (uint32_t)SUBSEQ_BITS);
     mark(1);
 
     SyncArgs sa;
@@ -1510,7 +1533,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     for (int t = 0; t < npass; ++t) {
         sa.pass = t;
         sa.chained = t == npass - 1 ? 1 : 0;
-        hipLaunchKernelGGL(k_sync_pass, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        hipLaunchKernelGGL(k_sync_pass<SB>, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
     }
     mark(2);
 
@@ -1532,13 +1555,25 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     wa.interval = L.restart_interval;
     wa.bslot = bslot;
     wa.status = L.d_status;
-    hipLaunchKernelGGL(k_write, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
+    hipLaunchKernelGGL(k_write<SB>, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);
     mark(5);
     ENT_HIP(hipGetLastError());
     S->part_clean = true;   // K1's last launch is enqueued
     return KPEG_HIP_OK;
 #undef ENT_HIP
+}
+
+// Dense streams (from 4 bits per pixel) re-synchronise over thousands of bits: K1 then needs many rounds, and
+// four times longer sub-sequences mean a quarter of the rounds (each with its fixed cost) for the same
+// sequential chain; K2 pays ~40 % for them, K1 gains more (measured 1..19 bits per pixel).
+static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, const EntropyLaunch& L, hipEvent_t* ev, bool* ev_rec,
+                                 std::string* err)
+{
+    const uint64_t bytes = L.nimg ? L.total_len : (uint64_t)L.scan_len;
+    const bool dense = L.subseq ? L.subseq >= SUBSEQ_DENSE : bytes * 8 >= (uint64_t)L.nmcu * 64 * 4;   // from 4 bits per pixel
+    return dense ? entropy_decode_launch_s<SUBSEQ_DENSE>(S, tabs, L, ev, ev_rec, err)
+                 : entropy_decode_launch_s<SUBSEQ_SPARSE>(S, tabs, L, ev, ev_rec, err);
 }
 
 }  // namespace kpeg_dev

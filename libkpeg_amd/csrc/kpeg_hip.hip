@@ -31,6 +31,7 @@ struct kpeg_hip_ctx {
     int idct_mode = 0;
     int sync_passes = 0;  // 0 = default number of enqueued sync passes
     int warm = -1;        // test hook: K1's warm-up sub-sequences per workgroup (< 0 = default)
+    int subseq = 0;       // test hook: K1/K2 sub-sequence size (0 = from the bit rate)
     int batch_chunk = 4096;  // images per fused-batch chunk (test hook: small values exercise the chunk loop)
     bool profiling = false;
     int num_cus = 256;
@@ -435,6 +436,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.num_cus = ctx->num_cus;
     L.sync_passes = ctx->sync_passes;
     L.warm = ctx->warm;
+    L.subseq = ctx->subseq;
     if (batch) {
         L.nimg = batch->nimg;
         L.d_scan_tab = batch->d_scan_tab;
@@ -532,6 +534,7 @@ static int ensure_lanes(kpeg_hip_ctx* ctx)
         ctx->lanes[l]->idct_mode = ctx->idct_mode;
         ctx->lanes[l]->sync_passes = ctx->sync_passes;
         ctx->lanes[l]->warm = ctx->warm;
+        ctx->lanes[l]->subseq = ctx->subseq;
     }
     for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
         if (!ctx->lane_ev[l]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
@@ -752,13 +755,15 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
 }
 
 // test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default),
-// key 3 = images per fused-batch chunk (0 = default)
+// key 3 = images per fused-batch chunk (0 = default), key 4 = sub-sequence size (0 = from the bit rate, else the sparse or the
+// dense size is forced)
 extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
 {
     if (!ctx) return KPEG_HIP_E_ARG;
     if (key == 1) ctx->sync_passes = value;
     else if (key == 2) ctx->warm = value;
     else if (key == 3) ctx->batch_chunk = value > 0 && value <= 4096 ? value : 4096;
+    else if (key == 4) ctx->subseq = value;
     else return KPEG_HIP_E_ARG;
     return KPEG_HIP_OK;
 }

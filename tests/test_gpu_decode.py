@@ -62,8 +62,18 @@ def test_extreme_geometries(ctx, w, h):
     assert np.array_equal(got, want)
 
 
-def test_random_sweep_against_the_oracle(ctx):
-    """Seeded sweep over sizes, qualities, noise levels, dense-noise mode and restart intervals (48 cases)."""
+@pytest.mark.parametrize("subseq", [0, 96, 384])
+def test_random_sweep_against_the_oracle(ctx, subseq):
+    """Seeded sweep over sizes, qualities, noise levels, dense-noise mode and restart intervals (48 cases), with
+    K1/K2's sub-sequence size chosen from the bit rate (0) and forced to the sparse and the dense size."""
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, subseq) == 0
+    try:
+        _random_sweep(ctx)
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 0)
+
+
+def _random_sweep(ctx):
     rng = np.random.default_rng(20240607)
     for case in range(48):
         w, h = int(rng.integers(1, 40)) * 8, int(rng.integers(1, 24)) * 8
@@ -153,6 +163,7 @@ import sys
 sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
 import numpy as np, kpeg_testlib as T, libkpeg_amd
 ctx = libkpeg_amd.Context(0)
+assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 64) == 0   # the stress build's small sub-sequences, whatever the bit rate
 worst = 0
 for (w, h, q, sigma, mode, warm) in [(1024, 512, 95, 0.0, 1, -1), (1024, 512, 95, 0.0, 1, 0), (1920, 1080, 75, 6.0, 0, 0), (512, 512, 30, 3.0, 0, -1)]:
     data = T.synth_jpeg(w, h, seed=21, quality=q, sigma=sigma, mode=mode)
