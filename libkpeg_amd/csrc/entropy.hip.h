@@ -809,7 +809,7 @@ __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list,
     if (m == 0) return;
     uint32_t base = 0;
     if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, 0);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
     if (want) list[base + rank] = (uint16_t)v;
 }
@@ -1042,12 +1042,13 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 // a predecessor re-decoded in this same round may or may not have stored its new
                 // exit state yet: either value is a valid start, and if it moved this item is on
                 // the next list again
+                const uint64_t before = s_X[j + 1];   // (read with the entry state: one LDS round trip, not two)
                 const RunResult r = run_count(T, s_bits, w0, unpack_state(s_X[j]), s_geo[j] & 0x7FFFFFFFu);
 #if KPEG_SYNC_STATS
                 st_runs++;
                 st_iters += r.iters;
 #endif
-                const bool changed = r.exit_state != s_X[j + 1];
+                const bool changed = r.exit_state != before;
                 s_X[j + 1] = r.exit_state;
                 if (j >= wu) s_cnt[j - wu] = r.cnt;
                 want = changed && j + 1 < nit && !(s_geo[j + 1] >> 31);
