@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kpeg_tables.h"
 
 namespace kpeg_dev {
@@ -146,55 +148,6 @@ __device__ __forceinline__ uint32_t colour_exact(int sy, int scb, int scr)
     return (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16);
 }
 
-// One sample of MCU::computeIDCT evaluated by a whole wavefront: lane p owns coefficient
-// position p = u*8+v (row-major = the reference's loop order), computes its product
-// term; the float accumulation then walks the non-zero lanes in order.
-// F: this lane's dequantised coefficient (int), x = pixel row, y = pixel column.
-// Returns S = (int)roundl(ic) + 128 in every lane.
-__device__ __forceinline__ int exact_sample_wave(int F, int x, int y)
-{
-    const int lane = __lane_id();
-    const int u = lane >> 3, v = lane & 7;
-    float fc = cc_of(u, v) * (float)F;                                 // float multiply
-    double t = ((double)fc * c_cos[x * 8 + u]) * c_cos[y * 8 + v];      // two double multiplies
-    unsigned long long live = __ballot(F != 0);
-    float sum = 0.0f;
-    while (live) {
-        int p = __builtin_ctzll(live);
-        live &= live - 1;
-        // p is wave-uniform: two v_readlane_b32
-        long long tb = __builtin_bit_cast(long long, t);
-        unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)tb, p);
-        unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), p);
-        double tp = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-        sum = (float)((double)sum + tp);
-    }
-    float ic = (float)(0.25 * (double)sum);
-    return level_shift(ic);
-}
-
-// Same, with the cosine table and the term's float factor supplied by the caller (K4 keeps the
-// tile's coefficients, the quantisers and the cosines in LDS: no global access on this path).
-__device__ __forceinline__ int exact_sample_wave_lds(float fc, const double* __restrict__ s_cos, int x, int y, bool nz)
-{
-    const int lane = __lane_id();
-    const int u = lane >> 3, v = lane & 7;
-    double t = ((double)fc * s_cos[x * 8 + u]) * s_cos[y * 8 + v];
-    unsigned long long live = __ballot(nz);
-    float sum = 0.0f;
-    while (live) {
-        int p = __builtin_ctzll(live);
-        live &= live - 1;
-        long long tb = __builtin_bit_cast(long long, t);
-        unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)tb, p);
-        unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), p);
-        double tp = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-        sum = (float)((double)sum + tp);
-    }
-    float ic = (float)(0.25 * (double)sum);
-    return level_shift(ic);
-}
-
 // ---- mode 1: reference-order evaluation of every sample (cross-check kernel) -----------
 // One 64-thread block per MCU, thread = pixel.  Slow by design.
 __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables qt)
@@ -300,18 +253,12 @@ __global__ __launch_bounds__(256) void k_ebound(const int16_t* coef, uint32_t nb
 
 typedef unsigned int uint3v __attribute__((ext_vector_type(3)));
 typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) uint4v;  // 16-byte view of uint32_t LDS words
-// int16 element k of a coefficient array kept as 32-bit words
-__device__ __forceinline__ int lds_coef(const uint32_t* w, int k)
-{
-    const uint32_t x = w[k >> 1];
-    return (k & 1) ? ((int)x >> 16) : (int)(short)(x & 0xFFFF);
-}
 constexpr int TILE_MCUS = 8;                    // MCUs per wavefront iteration (8 lane groups)
 constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 192
 constexpr int TILE_ROW_STRIDE = 208;            // padded: 13 x 16 bytes, conflict-free b64 writes across rows
-constexpr int QUEUE_CAP = 256;                  // queued pixels per tile; more -> whole-tile exact path
+constexpr int QUEUE_CAP = 256;                  // queued pixel positions per wavefront; a tile that overflows it is evaluated as a whole
 #ifndef KPEG_K4_OCC
-#define KPEG_K4_OCC 8
+#define KPEG_K4_OCC 5
 #endif
 constexpr int K4_WAVES_PER_CU = 4 * KPEG_K4_OCC;  // one wavefront per workgroup, KPEG_K4_OCC per SIMD
 
@@ -499,40 +446,63 @@ __device__ __forceinline__ uint32_t pk_u8(float v, uint32_t sel, uint32_t old)
     return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, old);  // saturating float -> byte `sel` of old
 }
 
-// Reference-order value of one sample of a block whose non-zero coefficients all lie in the 2x2
-// low-frequency corner: MCU::computeIDCT's sum (MCU.cpp:184-198) restricted to the terms (0,0), (0,1),
-// (1,0), (1,1) in that order -- the others are zero and leave the float accumulator unchanged, as do
-// zero terms among these four (x + (+-0) == x), so no test is needed.  cos((2x+1)*0*pi/16) == 1.0 exactly.
-//   w0 / w1: LDS words holding coefficients (0,0),(0,1) / (1,0),(1,1); q..: the four quantisers as float;
-//   cx1 = cosT[x][1], cy1 = cosT[y][1].  Returns roundl(ic) as a float (the sample minus the level shift).
-__device__ __forceinline__ float exact_corner(uint32_t w0, uint32_t w1, float q00, float q01, float q10, float q11, double cx1,
-                                              double cy1)
+// ---- reference-order evaluation of single samples, one lane per (pixel, component) -----------
+// MCU::computeIDCT's sum for one sample (MCU.cpp:184-198): u outer, v inner, every term two double multiplies,
+// accumulated in a float.  A zero coefficient adds +-0 and leaves the accumulator as it is: skipped.
+//   blk: the block's eight coefficient rows in global memory (natural order);
+//   qi:  the component's quantisers as int32, natural order (LDS);  s_cos: cosT as doubles (LDS);
+//   x, y: pixel row / column.   Returns (int)roundl(icoeffs[x][y]) + 128.
+// Called by all lanes of a fix-up pass together (lanes hold different pixels of different blocks): rows that are
+// zero on every lane are skipped as a whole.
+__device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, const uint32_t* __restrict__ qi,
+                                                 const double* __restrict__ s_cos, int x, int y)
 {
-    const float c0 = 0x1.6a09e6p-1f;  // (float)(1/sqrt 2)
-    const int F00 = (int)(short)(w0 & 0xFFFF) * (int)q00, F01 = ((int)w0 >> 16) * (int)q01;
-    const int F10 = (int)(short)(w1 & 0xFFFF) * (int)q10, F11 = ((int)w1 >> 16) * (int)q11;
-    const float fc00 = (c0 * c0) * (float)F00, fc01 = (c0 * 1.0f) * (float)F01, fc10 = (1.0f * c0) * (float)F10,
-                fc11 = (float)F11;
-    float sum = fc00;                                              // (float)(0.0 + fc00 * 1.0 * 1.0)
-    sum = (float)((double)sum + (double)fc01 * cy1);              // ((double)fc01 * 1.0) * cy1
-    sum = (float)((double)sum + (double)fc10 * cx1);              // ((double)fc10 * cx1) * 1.0
-    sum = (float)((double)sum + ((double)fc11 * cx1) * cy1);
-    const float ic = (float)(0.25 * (double)sum);
-    const float t = truncf(ic), fr = ic - t;
-    return t + (fr >= 0.5f ? 1.0f : 0.0f) - (fr <= -0.5f ? 1.0f : 0.0f);  // roundl: half away from zero
+    float sum = 0.0f;
+    uint4 next = blk[0];
+    // rolled on purpose (code size, registers: this runs once per ~10 tiles); the next row's load is in flight
+    // while a row is processed
+#pragma unroll 1
+    for (int u = 0; u < 8; ++u) {
+        const uint4 d = next;
+        if (u < 7) next = blk[u + 1];
+        if (__ballot((d.x | d.y | d.z | d.w) != 0) == 0) continue;  // wave-uniform
+        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+        const double cxu = s_cos[x * 8 + u];
+        const float cu = u == 0 ? 0x1.6a09e6p-1f : 1.0f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int cf = (v & 1) ? ((int)w[v >> 1] >> 16) : (int)(short)(w[v >> 1] & 0xFFFF);
+            if (cf != 0) {
+                const int F = cf * (int)qi[u * 8 + v];                             // m_8x8block after MCU.cpp:110-112
+                const float cc = cu * (v == 0 ? 0x1.6a09e6p-1f : 1.0f);    // Cf[u] * Cf[v] in float (cc_of)
+                const float fc = cc * (float)F;                            // float multiply (MCU.cpp:189-192)
+                const double t = ((double)fc * cxu) * s_cos[y * 8 + v];             // two double multiplies
+                sum = (float)((double)sum + t);                            // float accumulator
+            }
+        }
+    }
+    return level_shift((float)(0.25 * (double)sum));
 }
+
+constexpr int QUEUE_FLUSH = 21;   // 21 queued pixels x 3 components fill one fix-up pass (63 lanes)
 
 // One wavefront per workgroup: no workgroup barrier anywhere, every wave is an independent
 // worker walking its own tiles of 8 MCUs (64 x 8 pixels).  Small register footprint on purpose:
 // VALU issue on gfx950 needs >= 4 resident waves per SIMD to approach its rate
 // (tools/ubench/valu_rate.hip).
+//
+// Pixels whose fast value cannot be trusted (within the block's bound of a rounding boundary, or a G term too
+// close to an integer) are only *noted* in the tile loop: their position goes to a small queue in LDS.  Once the
+// tiles they belong to have been written out, a fix-up pass evaluates them in the reference's own order, one lane
+// per (pixel, component), and patches the three bytes in global memory.  Handling them where they are found -- a few
+// lanes of a wavefront, several times per tile -- cost 37 % of the kernel's time (profiles/r01_g: 0.103 -> 0.065 ms with
+// the handling compiled out).
 __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams p, QTables qt)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[8 * TILE_ROW_STRIDE];
-    __shared__ uint2 s_queue[QUEUE_CAP];
-    __shared__ __attribute__((aligned(16))) float s_m[2][64];  // AC input scales, natural order
-    __shared__ __attribute__((aligned(16))) uint32_t s_coef[TILE_MCUS * 96];  // the tile's coefficients (exact path)
-    __shared__ float s_qcc[2][64];                              // (float)Q (exact dequantisation on the exact path)
+    __shared__ uint32_t s_queue[QUEUE_CAP];
+    __shared__ __attribute__((aligned(16))) float s_m[2][64];     // AC input scales, natural order
+    __shared__ __attribute__((aligned(16))) uint32_t s_qi[2][64]; // quantisers (exact dequantisation in the fix-up pass)
     __shared__ double s_cos[64];
 
     const int tid = threadIdx.x;
@@ -543,7 +513,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     for (int i = tid; i < 128; i += 64) {
         const int t = i >> 6, k = i & 63;
         s_m[t][k] = 0.25f * cc_of(k >> 3, k & 7) * (float)qt.q[t][k];
-        s_qcc[t][k] = (float)qt.q[t][k];
+        s_qi[t][k] = qt.q[t][k];
     }
     s_cos[tid] = c_cos[tid];
     LaneConst lc;
@@ -563,20 +533,9 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     // combine: out = own + mirror * s.  Even lane x: E_x - (-O_x) -> s = -1;
     // odd lane (pixel row 7-x): E_x - O_x = mirror(E_x) + own(-O_x) -> s = +1.
     lc.s = lane8 < 4 ? -1.0f : 1.0f;
-    const double cx1 = c_cos[lane8 * 8 + 1];  // cosT[pixel row][1] for exact_corner
-    const float qy00 = (float)qt.q[0][0], qy01 = (float)qt.q[0][1], qy10 = (float)qt.q[0][8], qy11 = (float)qt.q[0][9];
-    const float qc00 = (float)qt.q[1][0], qc01 = (float)qt.q[1][1], qc10 = (float)qt.q[1][8], qc11 = (float)qt.q[1][9];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // MCU of this lane's group in a tile (groups beyond the image re-read the tile's first MCU;
-    // their pixels are never stored)
-    auto tile_mcu = [&](uint32_t tile) -> size_t {
-        const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
-        const uint32_t m0 = tcol * TILE_MCUS;
-        const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
-        return (size_t)trow * p.mcus_w + m0 + ((uint32_t)grp < nm ? grp : 0);
-    };
     // Coalesced write-back of a finished tile from LDS: 8 rows x nm*24 bytes as 16-byte chunks
     // (8 x 12 = 96 chunks: one per lane plus a second one on lanes 0..31; offsets fixed per lane).
     // It is issued one iteration late, ahead of the next loads, so that waiting for a tile's
@@ -606,7 +565,11 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         return (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
     };
     auto write_back = [&](size_t off, uint32_t nm) {
-        uint8_t* base = p.rgb + off;
+        // the tile's base stays a scalar pair and the lane's share a 32-bit offset (global_store with an SGPR base):
+        // left alone, the compiler adds p.rgb to every lane offset outside the loop and keeps 64-bit addresses in VGPRs
+        unsigned long long base_u = reinterpret_cast<uintptr_t>(p.rgb) + off;
+        asm volatile("" : "+s"(base_u));
+        uint8_t* base = reinterpret_cast<uint8_t*>(base_u);
         if (nm == TILE_MCUS && pitch16) {
 #ifdef KPEG_ABLATE_STORES
             if (p.ntiles == 1) *reinterpret_cast<uint4*>(base + wbA_g) = *reinterpret_cast<const uint4*>(s_tile + wbA_lds);
@@ -624,16 +587,70 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         }
     };
 
+    // Fix-up passes.  A position word names a pixel of one of this wavefront's tiles:
+    //   [2:0] MCU within the tile, [5:3] pixel row, [8:6] pixel column, [31:9] the tile's sequence number k
+    //   (tile = blockIdx.x + k * gridDim.x).
+    // nq queued positions, then -- if dense_nm != 0 -- every pixel of tile number dense_k (dense_nm MCUs).  Lane
+    // 3e + c of a pass evaluates component c of the pass's e-th pixel; lane 3e then converts and stores the pixel.
+    // The tiles concerned have been written out by this wavefront before (the caller waits for those stores).
+    auto run_fixups = [&](uint32_t nq, uint32_t dense_k, uint32_t dense_nm) {
+        uint32_t lane = (uint32_t)tid;
+        asm volatile("" : "+v"(lane));   // nothing of a fix-up pass is to be computed ahead of the tile loop and kept in registers
+        const uint32_t te = lane / 3u, tc = lane - te * 3u;
+        const uint32_t total = nq + dense_nm * 64u;
+        for (uint32_t base = 0; base < total; base += QUEUE_FLUSH) {
+            const uint32_t e = base + te;
+            const bool valid = lane < 3 * QUEUE_FLUSH && e < total;
+            uint32_t pos = 0;
+            if (valid) {
+                if (e < nq) pos = s_queue[e];
+                else {
+                    const uint32_t d = e - nq;   // g = d >> 6, x = (d >> 3) & 7, y = d & 7
+                    pos = (d >> 6) | (((d >> 3) & 7u) << 3) | ((d & 7u) << 6) | (dense_k << 9);
+                }
+            }
+            const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
+            const uint32_t tile = blockIdx.x + (pos >> 9) * gridDim.x;
+            const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
+            const uint32_t m0 = tcol * TILE_MCUS;
+            const size_t mcu = (size_t)trow * p.mcus_w + m0 + g;
+            int S = 0;
+            if (valid)
+                S = exact_sample_lane(reinterpret_cast<const uint4*>(p.coef) + (mcu * 3 + tc) * 8, s_qi[tc ? 1 : 0], s_cos, (int)x, (int)y);
+            const int S1 = __shfl_down(S, 1), S2 = __shfl_down(S, 2);
+            if (valid && tc == 0) {
+                const uint32_t px = colour_exact(S, S1, S2);
+                size_t off;
+                if (p.rgb_table) {
+                    const uint32_t img = trow / p.rows_per_img;
+                    off = (size_t)(reinterpret_cast<uintptr_t>(p.rgb_table[img]) - reinterpret_cast<uintptr_t>(p.rgb)) +
+                          (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch;
+                } else {
+                    off = (size_t)trow * 8 * p.pitch;
+                }
+                uint8_t* o = p.rgb + off + (size_t)x * p.pitch + (size_t)(m0 + g) * 24 + y * 3;
+                o[0] = (uint8_t)px;
+                o[1] = (uint8_t)(px >> 8);
+                o[2] = (uint8_t)(px >> 16);
+            }
+        }
+    };
+
     bool have_prev = false;
     size_t prev_off = 0;
     uint32_t prev_nm = 0;
+    uint32_t nq = 0;           // queued positions (wave-uniform)
+    uint32_t dense_nm = 0;     // != 0: the tile just computed has to be evaluated as a whole (its MCU count)
     uint32_t nq_total = 0;
-    for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (uint32_t tile = blockIdx.x, tilek = 0;; tile += gridDim.x, ++tilek) {
+        const bool more = tile < p.ntiles;
+        if (more) {
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
         const bool active = (uint32_t)grp < nm;
-        const size_t mcu = tile_mcu(tile);
+        // MCU of this lane's group (groups beyond the image re-read the tile's first MCU; their pixels are never stored)
+        const size_t mcu = (size_t)trow * p.mcus_w + m0 + (active ? grp : 0);
 #ifdef KPEG_ABLATE_LOADS
         const uint4 d0 = make_uint4(tile, tid, 0, 0), d1 = make_uint4(tid, 0, 0, 0), d2 = make_uint4(tile & 3, 0, 0, 0);
         const float e0 = 0.001f * (float)(mcu & 7), e1 = 0.0f, e2 = 0.0f;
@@ -642,20 +659,12 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         const uint4 d0 = src[0], d1 = src[8], d2 = src[16];
         const float e0 = p.ebound[mcu * 3], e1 = p.ebound[mcu * 3 + 1], e2 = p.ebound[mcu * 3 + 2];
 #endif
-
         const size_t cur_off = tile_offset(trow, m0);
         if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
         have_prev = true;
         prev_off = cur_off;
         prev_nm = nm;
-        {
-            // keep the tile's coefficients at hand for the exact path: block (grp, c), row u
-            // (plain uint32_t accesses on both sides: no type punning)
-            uint4v* sc = reinterpret_cast<uint4v*>(s_coef) + (grp * 3) * 8 + u;
-            sc[0] = (uint4v){d0.x, d0.y, d0.z, d0.w};
-            sc[8] = (uint4v){d1.x, d1.y, d1.z, d1.w};
-            sc[16] = (uint4v){d2.x, d2.y, d2.z, d2.w};
-        }
+
         float v[3][8];
 #ifdef KPEG_ABLATE_IDCT
         for (int i = 0; i < 8; ++i) {
@@ -674,8 +683,8 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
         else block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
 #endif
-        const float thr0 = 0.5f - fabsf(e0), thr1 = 0.5f - fabsf(e1), thr2 = 0.5f - fabsf(e2);
-        const bool sp0 = __float_as_uint(e0) >> 31, sp1 = __float_as_uint(e1) >> 31, sp2 = __float_as_uint(e2) >> 31;
+        // |fast - rint(fast)| + nthr >= 0  <=>  within the block's bound of a rounding boundary
+        const float nthr0 = fabsf(e0) - 0.5f, nthr1 = fabsf(e1) - 0.5f, nthr2 = fabsf(e2) - 0.5f;
         // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
         const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
         const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
@@ -684,96 +693,59 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         // whether the reference-order evaluation is needed (key >= 0): a fast value within its block's
         // bound of a rounding boundary, or a G term too close to an integer for the f32 arithmetic.
         // Nearly every wavefront has a few such pixels (true ties are structural: equal and opposite
-        // (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5 exactly), so they are
-        // queued straight from this loop with ballot compaction: no atomics, no second pass.
+        // (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5 exactly): their positions are
+        // queued straight from this loop with ballot compaction (no atomics, no second pass).
         uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
-        uint32_t nq = 0;
-        const uint32_t ent_lane = (uint32_t)grp | ((uint32_t)lane8 << 5);
+        const uint32_t nq_tile = nq;
+        const uint32_t pos_lane = (uint32_t)grp | ((uint32_t)lane8 << 3) | (tilek << 9);
         const unsigned long long active_mask = __ballot(active);
-        // colour of one pixel from its three rounded samples (minus the level shift); dt = how far the G
-        // term's t is from an integer, as seen by the f32 arithmetic (1.0 where G needs no check)
-        auto colour_of = [&](float ry, float rb, float rr, float& R, float& G, float& B, float& dt) {
-            const float yf = ry + 128.0f;
-            R = yf + floorf(rr * 1.402f);
-            B = yf + floorf(rb * 1.772f);
-            const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
-            G = yf - ceilf(t);
-            // distance of t to the nearest integer, except that t == 0 (Cb = Cr = 128, exact in the
-            // reference too) must not count: non-zero |t| is >= 8e-6, so 1 - |t| * 2^17 <= 0 there
-            dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
-            if (any_wide) {
-                if (wide) {
-                    // out of the f32 colour arithmetic's range: the reference's own double arithmetic on the rounded samples
-                    const uint32_t px = colour_exact((int)ry + 128, (int)rb + 128, (int)rr + 128);
-                    R = (float)(px & 0xFF);
-                    G = (float)((px >> 8) & 0xFF);
-                    B = (float)(px >> 16);
-                    dt = 1.0f;   // G is exact here
-                }
-            }
-        };
+        // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
+        auto pixel_loop = [&](auto with_wide) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
-            float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
-            // >= 0: the fast value is within its block's bound of a rounding boundary
-            float fy = fabsf(vy - ry) - thr0, fb = fabsf(vb - rb) - thr1, fr = fabsf(vr - rr) - thr2;
-            float R, G, B, dt;
-            colour_of(ry, rb, rr, R, G, B, dt);
-            float key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
-            pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
-            pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
-            pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
+            for (int i = 0; i < 8; ++i) {
+                const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
+                const float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
+                // >= 0: the fast value is within its block's bound of a rounding boundary
+                const float fy = fabsf(vy - ry) + nthr0, fb = fabsf(vb - rb) + nthr1, fr = fabsf(vr - rr) + nthr2;
+                // colour from the three rounded samples (minus the level shift); dt = how far the G term's t is from
+                // an integer, as seen by the f32 arithmetic
+                const float yf = ry + 128.0f;
+                float R = yf + floorf(rr * 1.402f);
+                float B = yf + floorf(rb * 1.772f);
+                const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
+                float G = yf - ceilf(t);
+                // distance of t to the nearest integer, except that t == 0 (Cb = Cr = 128, exact in the
+                // reference too) must not count: non-zero |t| is >= 8e-6, so 1 - |t| * 2^17 <= 0 there
+                float dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
+                if (decltype(with_wide)::value) {
+                    if (wide) {
+                        // out of the f32 colour arithmetic's range: the reference's own double arithmetic on the rounded samples
+                        const uint32_t px = colour_exact((int)ry + 128, (int)rb + 128, (int)rr + 128);
+                        R = (float)(px & 0xFF);
+                        G = (float)((px >> 8) & 0xFF);
+                        B = (float)(px >> 16);
+                        dt = 1.0f;   // G is exact here
+                    }
+                }
+                const float key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
+                pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
+                pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
+                pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
 #ifndef KPEG_ABLATE_PUSH
-            // one wave-uniform test per pixel column: nobody flagged -> next column
-            if (__builtin_amdgcn_fcmpf(key, 0.0f, 3 /* FCMP_OGE */) & active_mask) {
-                // corner-only blocks are settled here in reference order, by the lane that found the tie
-                bool fixed = false;
-                {
-                    const double cy1 = c_cos[i * 8 + 1];
-                    const uint32_t* blk = s_coef + grp * 96;
-                    if (fy >= 0.0f && sp0) {
-                        ry = exact_corner(blk[0], blk[4], qy00, qy01, qy10, qy11, cx1, cy1);
-                        fy = -1.0f;
-                        fixed = true;
-                    }
-                    if (fb >= 0.0f && sp1) {
-                        rb = exact_corner(blk[32], blk[36], qc00, qc01, qc10, qc11, cx1, cy1);
-                        fb = -1.0f;
-                        fixed = true;
-                    }
-                    if (fr >= 0.0f && sp2) {
-                        rr = exact_corner(blk[64], blk[68], qc00, qc01, qc10, qc11, cx1, cy1);
-                        fr = -1.0f;
-                        fixed = true;
-                    }
-                }
-                if (fixed) {
-                    colour_of(ry, rb, rr, R, G, B, dt);
-                    key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
-                    pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
-                    pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
-                    pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
-                }
-                // the others are queued for the wavefront (ballot compaction: no atomics, no second pass)
-                const bool push = active && key >= 0.0f;
-                const unsigned long long bal = __ballot(push);
-                if (bal) {  // wave-uniform
+                // one wave-uniform test per pixel column: nobody flagged -> next column
+                const unsigned long long bal = __builtin_amdgcn_fcmpf(key, 0.0f, 3 /* FCMP_OGE */) & active_mask;
+                if (bal) {
                     const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                    if (push && slot < QUEUE_CAP) {
-                        // entry.x: [2:0] mcu in tile, [7:5] pixel row, [10:8] pixel col, [13:11] components to
-                        // re-evaluate, [31:16] rint(vY); entry.y: rint(vCb) | rint(vCr) << 16 (all |.| < 32000)
-                        const uint32_t mask = (fy >= 0.0f ? 1u : 0u) | (fb >= 0.0f ? 2u : 0u) | (fr >= 0.0f ? 4u : 0u);
-                        s_queue[slot] = make_uint2(ent_lane | ((uint32_t)i << 8) | (mask << 11) | ((uint32_t)(int)ry << 16),
-                                                   ((uint32_t)(int)rb & 0xFFFFu) | ((uint32_t)(int)rr << 16));
-                    }
+                    if (key >= 0.0f && active && slot < QUEUE_CAP) s_queue[slot] = pos_lane | ((uint32_t)i << 6);
                     nq += __popcll(bal);
                 }
-            }
 #else
-            (void)key;
+                (void)key;
 #endif
-        }
+            }
+        };
+        if (any_wide) pixel_loop(std::true_type{});
+        else pixel_loop(std::false_type{});
 
         {
             // 24 bytes of pixel row lane8, MCU grp (groups beyond nm write garbage that is never stored)
@@ -782,67 +754,30 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             dst[1] = make_uint2(pk[2], pk[3]);
             dst[2] = make_uint2(pk[4], pk[5]);
         }
-
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // exact re-evaluation by the whole wavefront, one queued pixel at a time, flagged components only
-        if (nq && !p.skip_exact) {
-            const float ccl = cc_of(tid >> 3, tid & 7);
-            if (nq > QUEUE_CAP) {
-                // more unsafe pixels than the queue holds (adversarial input): every pixel of the tile
-                for (uint32_t e = 0; e < (uint32_t)nm * 64; ++e) {
-                    const int g = e >> 6, x = (e >> 3) & 7, y = e & 7;
-                    int S[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        // (float)(c * Q) is exact here: the product of two integers below 2^24 ... or rounds like the int would
-                        const int F = lds_coef(s_coef, (g * 3 + c) * 64 + tid) * (int)s_qcc[c ? 1 : 0][tid];
-                        S[c] = exact_sample_wave_lds(ccl * (float)F, s_cos, x, y, F != 0);
-                    }
-                    if (tid == 0) {
-                        const uint32_t px = colour_exact(S[0], S[1], S[2]);
-                        uint8_t* o = s_tile + x * TILE_ROW_STRIDE + g * 24 + y * 3;
-                        o[0] = (uint8_t)px;
-                        o[1] = (uint8_t)(px >> 8);
-                        o[2] = (uint8_t)(px >> 16);
-                    }
-                }
-            } else {
-                for (uint32_t e = 0; e < nq; ++e) {
-                    const uint2 ent = s_queue[e];
-                    const int g = ent.x & 7, x = (ent.x >> 5) & 7, y = (ent.x >> 8) & 7;
-                    const uint32_t mask = (ent.x >> 11) & 7;
-                    // unflagged components: rint(fast value) is provably the reference's rounding
-                    int S[3] = {(int)(short)(ent.x >> 16) + 128, (int)(short)(ent.y & 0xFFFF) + 128, (int)(short)(ent.y >> 16) + 128};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (mask & (1u << c)) {  // wave-uniform
-                            const int F = lds_coef(s_coef, (g * 3 + c) * 64 + tid) * (int)s_qcc[c ? 1 : 0][tid];
-                            S[c] = exact_sample_wave_lds(ccl * (float)F, s_cos, x, y, F != 0);
-#ifdef KPEG_DEBUG_EXACT
-                            if (tile == 1 && e == 0 && p.stats) {
-                                p.stats[64 + tid] = (uint32_t)F;
-                                p.stats[128 + tid] = (uint32_t)p.coef[((size_t)(trow * p.mcus_w + m0 + g) * 3 + c) * 64 + tid];
-                                if (tid == 0) { p.stats[200] = ent.x; p.stats[201] = ent.y; p.stats[202] = (uint32_t)S[c]; p.stats[203] = c; }
-                            }
-#endif
-                        }
-                    }
-                    if (tid == 0) {
-                        const uint32_t px = colour_exact(S[0], S[1], S[2]);
-                        uint8_t* o = s_tile + x * TILE_ROW_STRIDE + g * 24 + y * 3;
-                        o[0] = (uint8_t)px;
-                        o[1] = (uint8_t)(px >> 8);
-                        o[2] = (uint8_t)(px >> 16);
-                    }
-                }
-            }
+        nq_total += nq - nq_tile;
+        if (nq > QUEUE_CAP) {
+            // more unsafe pixels than the queue takes (adversarial input, extreme coefficients): the tile's own
+            // entries are dropped and every pixel of the tile is evaluated in reference order once it is written out
+            nq_total += nm * 64u - (nq - nq_tile);
+            nq = nq_tile;
+            dense_nm = nm;
         }
-        nq_total += nq;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the next iteration writes this tile back before its own colour phase overwrites the LDS tile
+        }
+        // Fix-ups are due: a pass's worth of queued pixels, a dense tile, or the end of this wavefront's tiles.  Few
+        // values of the tile loop are live here.  Every tile a queued position refers to must have been stored, and
+        // the stores performed, before the fix-ups overwrite bytes of theirs.
+        if (nq >= QUEUE_FLUSH || dense_nm || (!more && nq)) {   // wave-uniform
+            if (have_prev) write_back(prev_off, prev_nm);
+            have_prev = false;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!p.skip_exact) run_fixups(nq, tilek, dense_nm);
+            nq = 0;
+            dense_nm = 0;
+        }
+        if (!more) break;
     }
     if (have_prev) write_back(prev_off, prev_nm);
     // one fire-and-forget add per wavefront, spread over 256 words (a single hot word serialises in L2)

@@ -35,6 +35,7 @@ struct kpeg_hip_ctx {
     int batch_chunk = 4096;  // images per fused-batch chunk (test hook: small values exercise the chunk loop)
     bool profiling = false;
     int num_cus = 256;
+    int k4_waves_per_cu = K4_WAVES_PER_CU;  // K4's grid = num_cus * this (create: what the device keeps resident)
 
     // device scratch (grown on demand, never shrunk)
     void* d_coef = nullptr;
@@ -149,6 +150,17 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
         return KPEG_HIP_E_DEVICE;
     }
     ctx->num_cus = prop.multiProcessorCount;
+    {
+        // K4's wavefronts are persistent workers: launch exactly as many as stay resident (more would run as a
+        // second, partly filled round).  KPEG_K4_WAVES_PER_CU: timing experiments only.
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_idct_colour_fast, 64, 0) == hipSuccess && nb > 0) ctx->k4_waves_per_cu = nb;
+        if (const char* s = std::getenv("KPEG_K4_WAVES_PER_CU")) {
+            const int v = std::atoi(s);
+            if (v > 0) ctx->k4_waves_per_cu = v;
+        }
+        if (std::getenv("KPEG_DEBUG")) std::fprintf(stderr, "kpeg_hip: K4 wavefronts per CU: %d (occupancy query %d)\n", ctx->k4_waves_per_cu, nb);
+    }
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return fail("hipStreamCreate", e);
     ctx->stream = ctx->own_stream;
@@ -345,7 +357,7 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
             p.tiles_w_magic = d > 1 ? (uint32_t)((((uint64_t)1 << (32 + sft)) + d - 1) / d) : 0;
             p.tiles_w_shift = sft;
         }
-        const uint32_t resident = (uint32_t)ctx->num_cus * K4_WAVES_PER_CU;  // one wavefront per workgroup
+        const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)ctx->k4_waves_per_cu;  // one wavefront per workgroup
         const uint32_t grid = p.ntiles < resident ? p.ntiles : resident;
         hipLaunchKernelGGL(k_idct_colour_fast, dim3(grid), dim3(64), 0, ctx->stream, p, qt);
     }
