@@ -256,7 +256,7 @@ typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) uint4v;  // 
 constexpr int TILE_MCUS = 8;                    // MCUs per wavefront iteration (8 lane groups)
 constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 192
 constexpr int TILE_ROW_STRIDE = 208;            // padded: 13 x 16 bytes, conflict-free b64 writes across rows
-constexpr int QUEUE_CAP = 256;                  // queued pixel positions per wavefront; a tile that overflows it is evaluated as a whole
+constexpr int QUEUE_CAP = 64;                   // queue entries per wavefront (fix-ups run from QUEUE_FLUSH entries on); pixels beyond go to the overflow list
 #ifndef KPEG_K4_OCC
 #define KPEG_K4_OCC 5
 #endif
@@ -446,45 +446,100 @@ __device__ __forceinline__ uint32_t pk_u8(float v, uint32_t sel, uint32_t old)
     return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, old);  // saturating float -> byte `sel` of old
 }
 
-// ---- reference-order evaluation of single samples, one lane per (pixel, component) -----------
-// MCU::computeIDCT's sum for one sample (MCU.cpp:184-198): u outer, v inner, every term two double multiplies,
-// accumulated in a float.  A zero coefficient adds +-0 and leaves the accumulator as it is: skipped.
-//   blk: the block's eight coefficient rows in global memory (natural order);
-//   qi:  the component's quantisers as int32, natural order (LDS);  s_cos: cosT as doubles (LDS);
-//   x, y: pixel row / column.   Returns (int)roundl(icoeffs[x][y]) + 128.
-// Called by all lanes of a fix-up pass together (lanes hold different pixels of different blocks): rows that are
-// zero on every lane are skipped as a whole.
+// ---- reference-order evaluation of single samples (the fix-up passes) ---------------------------
+// Value of one sample of a block whose non-zero coefficients all lie in the 2x2 low-frequency corner:
+// MCU::computeIDCT's sum (MCU.cpp:184-198) restricted to the terms (0,0), (0,1), (1,0), (1,1) in that order --
+// the others are zero and leave the float accumulator unchanged, as do zero terms among these four
+// (x + (+-0) == x), so no test is needed.  cos((2x+1)*0*pi/16) == 1.0 exactly.
+//   w0 / w1: the words holding coefficients (0,0),(0,1) / (1,0),(1,1); q..: the four quantisers;
+//   cx1 = cosT[x][1], cy1 = cosT[y][1].  Returns roundl(ic) as a float (the sample minus the level shift).
+// One lane per sample: nearly all unsafe pixels are of this kind (structural ties, see the kernel).
+__device__ __forceinline__ float exact_corner(uint32_t w0, uint32_t w1, uint32_t q00, uint32_t q01, uint32_t q10, uint32_t q11,
+                                              double cx1, double cy1)
+{
+    const float c0 = 0x1.6a09e6p-1f;  // (float)(1/sqrt 2)
+    const int F00 = (int)(short)(w0 & 0xFFFF) * (int)q00, F01 = ((int)w0 >> 16) * (int)q01;
+    const int F10 = (int)(short)(w1 & 0xFFFF) * (int)q10, F11 = ((int)w1 >> 16) * (int)q11;
+    const float fc00 = (c0 * c0) * (float)F00, fc01 = (c0 * 1.0f) * (float)F01, fc10 = (1.0f * c0) * (float)F10,
+                fc11 = (float)F11;
+    float sum = fc00;                                              // (float)(0.0 + fc00 * 1.0 * 1.0)
+    sum = (float)((double)sum + (double)fc01 * cy1);              // ((double)fc01 * 1.0) * cy1
+    sum = (float)((double)sum + (double)fc10 * cx1);              // ((double)fc10 * cx1) * 1.0
+    sum = (float)((double)sum + ((double)fc11 * cx1) * cy1);
+    const float ic = (float)(0.25 * (double)sum);
+    const float t = truncf(ic), fr = ic - t;
+    return t + (fr >= 0.5f ? 1.0f : 0.0f) - (fr <= -0.5f ? 1.0f : 0.0f);  // roundl: half away from zero
+}
+
+// One sample of any block, evaluated by the whole wavefront: lane p owns coefficient position p = u*8+v
+// (row-major = the reference's loop order) and computes its product term; the float accumulation then walks
+// the non-zero lanes in order.  fc: cc * (float)(coefficient * Q) of this lane's position; x, y wave-uniform.
+// Returns (int)roundl(ic) + 128 in every lane.
+__device__ __forceinline__ int exact_sample_wave(float fc, const double* __restrict__ s_cos, int x, int y, bool nz)
+{
+    const int lane = __lane_id();
+    const int u = lane >> 3, v = lane & 7;
+    const double t = ((double)fc * s_cos[x * 8 + u]) * s_cos[y * 8 + v];
+    unsigned long long live = __ballot(nz);
+    float sum = 0.0f;
+    while (live) {
+        const int p = __builtin_ctzll(live);
+        live &= live - 1;
+        // p is wave-uniform: two v_readlane_b32
+        const long long tb = __builtin_bit_cast(long long, t);
+        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)tb, p);
+        const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), p);
+        const double tp = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        sum = (float)((double)sum + tp);
+    }
+    return level_shift((float)(0.25 * (double)sum));
+}
+
+// One sample of any block, evaluated by one lane: the 64-term sum in the reference's order (u outer, v inner), zero
+// coefficients skipped (they leave the float accumulator unchanged).  Used when many samples are due at once (a tile
+// evaluated as a whole): every lane of a pass holds a different sample; rows that are zero on every lane are skipped.
+//   blk: the block's eight coefficient rows in global memory (natural order); qi: the component's quantisers (LDS).
 __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, const uint32_t* __restrict__ qi,
                                                  const double* __restrict__ s_cos, int x, int y)
 {
     float sum = 0.0f;
-    uint4 next = blk[0];
-    // rolled on purpose (code size, registers: this runs once per ~10 tiles); the next row's load is in flight
-    // while a row is processed
+    // two halves of four rows, each half's loads in flight together (all eight would need more registers than the
+    // tile loop leaves; one after the other is eight memory latencies)
 #pragma unroll 1
-    for (int u = 0; u < 8; ++u) {
-        const uint4 d = next;
-        if (u < 7) next = blk[u + 1];
-        if (__ballot((d.x | d.y | d.z | d.w) != 0) == 0) continue;  // wave-uniform
-        const uint32_t w[4] = {d.x, d.y, d.z, d.w};
-        const double cxu = s_cos[x * 8 + u];
-        const float cu = u == 0 ? 0x1.6a09e6p-1f : 1.0f;
+    for (int h = 0; h < 2; ++h) {
+        uint4 rows[4];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int cf = (v & 1) ? ((int)w[v >> 1] >> 16) : (int)(short)(w[v >> 1] & 0xFFFF);
-            if (cf != 0) {
-                const int F = cf * (int)qi[u * 8 + v];                             // m_8x8block after MCU.cpp:110-112
-                const float cc = cu * (v == 0 ? 0x1.6a09e6p-1f : 1.0f);    // Cf[u] * Cf[v] in float (cc_of)
-                const float fc = cc * (float)F;                            // float multiply (MCU.cpp:189-192)
-                const double t = ((double)fc * cxu) * s_cos[y * 8 + v];             // two double multiplies
-                sum = (float)((double)sum + t);                            // float accumulator
+        for (int k = 0; k < 4; ++k) rows[k] = blk[h * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 d = rows[k];
+            if (__ballot((d.x | d.y | d.z | d.w) != 0) == 0) continue;  // wave-uniform
+            const int u = h * 4 + k;
+            const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+            const double cxu = s_cos[x * 8 + u];
+            const float cu = u == 0 ? 0x1.6a09e6p-1f : 1.0f;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int cf = (v & 1) ? ((int)w[v >> 1] >> 16) : (int)(short)(w[v >> 1] & 0xFFFF);
+                if (cf != 0) {
+                    const int F = cf * (int)qi[u * 8 + v];                     // m_8x8block after MCU.cpp:110-112
+                    const float cc = cu * (v == 0 ? 0x1.6a09e6p-1f : 1.0f);    // Cf[u] * Cf[v] in float (cc_of)
+                    const float fc = cc * (float)F;                            // float multiply (MCU.cpp:189-192)
+                    const double t = ((double)fc * cxu) * s_cos[y * 8 + v];    // two double multiplies
+                    sum = (float)((double)sum + t);                            // float accumulator
+                }
             }
         }
     }
     return level_shift((float)(0.25 * (double)sum));
 }
 
-constexpr int QUEUE_FLUSH = 21;   // 21 queued pixels x 3 components fill one fix-up pass (63 lanes)
+#ifndef KPEG_QUEUE_FLUSH
+#define KPEG_QUEUE_FLUSH 32
+#endif
+constexpr int QUEUE_FLUSH = KPEG_QUEUE_FLUSH;   // queued pixels that make a fix-up pass worth its fixed cost
+constexpr int OVER_CAP = TILE_MCUS * 64 - (QUEUE_CAP - QUEUE_FLUSH);   // a tile starts with at least QUEUE_CAP - QUEUE_FLUSH free entries
+constexpr int QUEUE_WORDS = 8;    // per queued pixel: position, 3 rounded samples, 3 keys (>= 0: that component is unsafe), pad
 
 // One wavefront per workgroup: no workgroup barrier anywhere, every wave is an independent
 // worker walking its own tiles of 8 MCUs (64 x 8 pixels).  Small register footprint on purpose:
@@ -500,7 +555,9 @@ constexpr int QUEUE_FLUSH = 21;   // 21 queued pixels x 3 components fill one fi
 __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams p, QTables qt)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[8 * TILE_ROW_STRIDE];
-    __shared__ uint32_t s_queue[QUEUE_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_queue[QUEUE_CAP * QUEUE_WORDS];
+    __shared__ uint16_t s_over[OVER_CAP];   // unsafe pixels a tile has beyond the queue's room: bits [11:0] of the position word (the
+                                            // fix-up pass that takes them runs before the next tile: the tile is known)
     __shared__ __attribute__((aligned(16))) float s_m[2][64];     // AC input scales, natural order
     __shared__ __attribute__((aligned(16))) uint32_t s_qi[2][64]; // quantisers (exact dequantisation in the fix-up pass)
     __shared__ double s_cos[64];
@@ -537,13 +594,11 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     __builtin_amdgcn_wave_barrier();
 
     // Coalesced write-back of a finished tile from LDS: 8 rows x nm*24 bytes as 16-byte chunks
-    // (8 x 12 = 96 chunks: one per lane plus a second one on lanes 0..31; offsets fixed per lane).
+    // (8 x 12 = 96 chunks: lanes 0..47 store chunk k of row r and of row r + 4; two registers per lane hold it all).
     // It is issued one iteration late, ahead of the next loads, so that waiting for a tile's
     // coefficients never waits for the stores that follow them in issue order.
-    const uint32_t wbA_r = tid / 12, wbA_k = tid - wbA_r * 12;
-    const uint32_t wbB_r = (tid + 64) / 12, wbB_k = (tid + 64) - wbB_r * 12;
-    const uint32_t wbA_lds = wbA_r * TILE_ROW_STRIDE + wbA_k * 16, wbA_g = wbA_r * p.pitch + wbA_k * 16;
-    const uint32_t wbB_lds = wbB_r * TILE_ROW_STRIDE + wbB_k * 16, wbB_g = wbB_r * p.pitch + wbB_k * 16;
+    const uint32_t wb_r = (uint32_t)tid / 12u, wb_k = (uint32_t)tid - wb_r * 12u;
+    const uint32_t wb_lds = wb_r * TILE_ROW_STRIDE + wb_k * 16, wb_g = wb_r * p.pitch + wb_k * 16;
     const bool pitch16 = ((reinterpret_cast<uintptr_t>(p.rgb) | p.pitch) & 15) == 0;
     // Where a tile's pixels go, as an offset from the kernel argument p.rgb -- also in table mode: a pointer
     // loaded from memory has no known address space, its stores would be flat_store, and LDS waits wait for
@@ -565,18 +620,20 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         return (size_t)trow * 8 * p.pitch + (size_t)m0 * 24;
     };
     auto write_back = [&](size_t off, uint32_t nm) {
-        // the tile's base stays a scalar pair and the lane's share a 32-bit offset (global_store with an SGPR base):
-        // left alone, the compiler adds p.rgb to every lane offset outside the loop and keeps 64-bit addresses in VGPRs
-        unsigned long long base_u = reinterpret_cast<uintptr_t>(p.rgb) + off;
-        asm volatile("" : "+s"(base_u));
-        uint8_t* base = reinterpret_cast<uint8_t*>(base_u);
+        // the lane's share of a tile stays a 32-bit offset added to a scalar base (global_store with an SGPR base):
+        // left alone, the compiler adds p.rgb to every lane offset ahead of the loop and keeps 64-bit addresses in VGPRs
+        uint32_t oA = wb_g;
+        asm volatile("" : "+v"(oA));
+        uint8_t* base = p.rgb + off;
         if (nm == TILE_MCUS && pitch16) {
+            if (tid < 48) {
 #ifdef KPEG_ABLATE_STORES
-            if (p.ntiles == 1) *reinterpret_cast<uint4*>(base + wbA_g) = *reinterpret_cast<const uint4*>(s_tile + wbA_lds);
+                if (p.ntiles == 1) *reinterpret_cast<uint4*>(base + oA) = *reinterpret_cast<const uint4*>(s_tile + wb_lds);
 #else
-            *reinterpret_cast<uint4*>(base + wbA_g) = *reinterpret_cast<const uint4*>(s_tile + wbA_lds);
-            if (tid < 32) *reinterpret_cast<uint4*>(base + wbB_g) = *reinterpret_cast<const uint4*>(s_tile + wbB_lds);
+                *reinterpret_cast<uint4*>(base + oA) = *reinterpret_cast<const uint4*>(s_tile + wb_lds);
+                *reinterpret_cast<uint4*>(base + (size_t)4 * p.pitch + oA) = *reinterpret_cast<const uint4*>(s_tile + wb_lds + 4 * TILE_ROW_STRIDE);
 #endif
+            }
         } else {
             const uint32_t per_row = nm * 6;  // 4-byte pieces
             for (uint32_t c = tid; c < 8 * per_row; c += 64) {
@@ -587,39 +644,140 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         }
     };
 
-    // Fix-up passes.  A position word names a pixel of one of this wavefront's tiles:
-    //   [2:0] MCU within the tile, [5:3] pixel row, [8:6] pixel column, [31:9] the tile's sequence number k
-    //   (tile = blockIdx.x + k * gridDim.x).
-    // nq queued positions, then -- if dense_nm != 0 -- every pixel of tile number dense_k (dense_nm MCUs).  Lane
-    // 3e + c of a pass evaluates component c of the pass's e-th pixel; lane 3e then converts and stores the pixel.
-    // The tiles concerned have been written out by this wavefront before (the caller waits for those stores).
-    auto run_fixups = [&](uint32_t nq, uint32_t dense_k, uint32_t dense_nm) {
+    // Fix-up passes.  A queue entry is a pixel of one of this wavefront's tiles:
+    //   word 0: [2:0] MCU within the tile, [5:3] pixel row, [8:6] pixel column, [11:9] component blocks that are
+    //           corner-only (the sign of their bound), [31:12] the tile's sequence number k (tile = blockIdx.x + k * gridDim.x);
+    //   words 1..3: the three rounded fast samples (minus the level shift); words 4..6: their keys (>= 0: unsafe).
+    // nq queued entries, then nover pixels of the overflow list: position words only (a tile with more unsafe pixels
+    // than the queue had room for: clusters of ties, adversarial input), all components to be evaluated.  One lane per entry.  Unsafe components of corner-only blocks are settled by the lane itself
+    // with the four-term sum; the others (a few per wavefront) by the whole wavefront, one after the other; the lane
+    // then converts and stores its pixel.
+    // The tiles concerned have been written out by this wavefront before.
+    auto run_fixups = [&](uint32_t nq, uint32_t nover, uint32_t over_k) {
         uint32_t lane = (uint32_t)tid;
         asm volatile("" : "+v"(lane));   // nothing of a fix-up pass is to be computed ahead of the tile loop and kept in registers
-        const uint32_t te = lane / 3u, tc = lane - te * 3u;
-        const uint32_t total = nq + dense_nm * 64u;
-        for (uint32_t base = 0; base < total; base += QUEUE_FLUSH) {
-            const uint32_t e = base + te;
-            const bool valid = lane < 3 * QUEUE_FLUSH && e < total;
+        const uint32_t total = nq + nover;
+        const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
+        for (uint32_t base = 0; base < total; base += 64) {
+            const uint32_t e = base + lane;
+            const bool valid = e < total;
             uint32_t pos = 0;
+            float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, f0 = -1.0f, f1 = -1.0f, f2 = -1.0f;
             if (valid) {
-                if (e < nq) pos = s_queue[e];
-                else {
-                    const uint32_t d = e - nq;   // g = d >> 6, x = (d >> 3) & 7, y = d & 7
-                    pos = (d >> 6) | (((d >> 3) & 7u) << 3) | ((d & 7u) << 6) | (dense_k << 9);
+                if (e < nq) {
+                    const uint4v a = *reinterpret_cast<const uint4v*>(s_queue + e * QUEUE_WORDS);
+                    const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QUEUE_WORDS + 4);
+                    pos = a.x;
+                    r0 = __uint_as_float(a.y), r1 = __uint_as_float(a.z), r2 = __uint_as_float(a.w);
+                    f0 = __uint_as_float(b.x), f1 = __uint_as_float(b.y), f2 = __uint_as_float(b.z);
+                } else {
+                    pos = (uint32_t)s_over[e - nq] | (over_k << 12);
+                    f0 = f1 = f2 = 1.0f;
                 }
             }
             const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
-            const uint32_t tile = blockIdx.x + (pos >> 9) * gridDim.x;
+            const uint32_t tile = blockIdx.x + (pos >> 12) * gridDim.x;
             const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
             const uint32_t m0 = tcol * TILE_MCUS;
-            const size_t mcu = (size_t)trow * p.mcus_w + m0 + g;
-            int S = 0;
-            if (valid)
-                S = exact_sample_lane(reinterpret_cast<const uint4*>(p.coef) + (mcu * 3 + tc) * 8, s_qi[tc ? 1 : 0], s_cos, (int)x, (int)y);
-            const int S1 = __shfl_down(S, 1), S2 = __shfl_down(S, 2);
-            if (valid && tc == 0) {
-                const uint32_t px = colour_exact(S, S1, S2);
+            const uint32_t mcu = trow * p.mcus_w + m0 + g;
+            const bool need0 = f0 >= 0.0f, need1 = f1 >= 0.0f, need2 = f2 >= 0.0f;
+            // corner-only blocks: the two words such a block consists of
+#ifdef KPEG_FX_SKIP_CORNER
+            const bool cn0 = false, cn1 = false, cn2 = false;
+#else
+            const bool cn0 = need0 && (pos & (1u << 9)), cn1 = need1 && (pos & (1u << 10)), cn2 = need2 && (pos & (1u << 11));
+#endif
+            const uint32_t* c32 = reinterpret_cast<const uint32_t*>(p.coef) + (size_t)mcu * 96;
+            uint32_t w00 = 0, w01 = 0, w10 = 0, w11 = 0, w20 = 0, w21 = 0;
+            if (cn0) w00 = c32[0], w01 = c32[4];
+            if (cn1) w10 = c32[32], w11 = c32[36];
+            if (cn2) w20 = c32[64], w21 = c32[68];
+            // the others: wave-uniform lists of (lane, component)
+            unsigned long long g0 = __ballot(need0 && !cn0), g1 = __ballot(need1 && !cn1), g2 = __ballot(need2 && !cn2);
+#ifdef KPEG_FX_SKIP_COOP
+            g0 = g1 = g2 = 0;
+#endif
+            auto pop = [](unsigned long long& m0_, unsigned long long& m1_, unsigned long long& m2_, uint32_t& c, uint32_t& L) {
+                unsigned long long& mm = m0_ ? m0_ : (m1_ ? m1_ : m2_);
+                c = m0_ ? 0u : (m1_ ? 1u : 2u);
+                L = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+            };
+            const int16_t* c16 = p.coef;
+            constexpr int BATCH = 12;
+            const bool many = __popcll(g0) + __popcll(g1) + __popcll(g2) > BATCH;   // wave-uniform
+            // a batch of those: one coalesced 128-byte load per sample, all in flight together with the corner words
+            // (one memory latency per pass -- at the end of a wavefront's life nothing hides it)
+            int cf[BATCH];
+            unsigned long long a0 = g0, a1 = g1, a2 = g2;
+            if (!many) {
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    cf[k] = 0;
+                    if (a0 | a1 | a2) {
+                        uint32_t c, L;
+                        pop(a0, a1, a2, c, L);
+                        const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
+                        cf[k] = c16[((size_t)mcuL * 3 + c) * 64 + lane];
+                    }
+                }
+            }
+            const double cx1 = s_cos[x * 8 + 1], cy1 = s_cos[y * 8 + 1];
+            if (cn0) r0 = exact_corner(w00, w01, s_qi[0][0], s_qi[0][1], s_qi[0][8], s_qi[0][9], cx1, cy1);
+            if (cn1) r1 = exact_corner(w10, w11, s_qi[1][0], s_qi[1][1], s_qi[1][8], s_qi[1][9], cx1, cy1);
+            if (cn2) r2 = exact_corner(w20, w21, s_qi[1][0], s_qi[1][1], s_qi[1][8], s_qi[1][9], cx1, cy1);
+            if (many) {
+                // a tile evaluated as a whole, a cluster of unsafe pixels: every lane its own samples, component by component
+#pragma unroll 1
+                for (int c = 0; c < 3; ++c) {
+                    const bool nd = c == 0 ? (need0 && !cn0) : (c == 1 ? (need1 && !cn1) : (need2 && !cn2));
+                    if (__ballot(nd) == 0) continue;
+                    int S = 128;
+                    if (nd) S = exact_sample_lane(reinterpret_cast<const uint4*>(p.coef) + ((size_t)mcu * 3 + c) * 8, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
+                    const float rv = (float)(S - 128);
+                    if (nd) {
+                        if (c == 0) r0 = rv;
+                        else if (c == 1) r1 = rv;
+                        else r2 = rv;
+                    }
+                }
+            } else {
+                // by the whole wavefront, one sample after the other, lane = coefficient position
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        if (g0 | g1 | g2) {   // wave-uniform
+                            uint32_t c, L;
+                            pop(g0, g1, g2, c, L);
+                            const int xL = __builtin_amdgcn_readlane((int)x, (int)L), yL = __builtin_amdgcn_readlane((int)y, (int)L);
+                            const int F = cf[k] * (int)s_qi[c ? 1 : 0][lane];          // m_8x8block after MCU.cpp:110-112
+                            const int S = exact_sample_wave(ccl * (float)F, s_cos, xL, yL, F != 0);
+                            const float rv = (float)(S - 128);
+                            if (lane == L) {
+                                if (c == 0) r0 = rv;
+                                else if (c == 1) r1 = rv;
+                                else r2 = rv;
+                            }
+                        }
+                    }
+                    if (!(g0 | g1 | g2)) break;
+                    // the next batch (clusters only)
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        cf[k] = 0;
+                        if (a0 | a1 | a2) {
+                            uint32_t c, L;
+                            pop(a0, a1, a2, c, L);
+                            const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
+                            cf[k] = c16[((size_t)mcuL * 3 + c) * 64 + lane];
+                        }
+                    }
+                }
+            }
+            // the tile's own stores (issued before this pass's loads) must have been performed before bytes of theirs are patched
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (valid) {
+                const uint32_t px = colour_exact((int)r0 + 128, (int)r1 + 128, (int)r2 + 128);
                 size_t off;
                 if (p.rgb_table) {
                     const uint32_t img = trow / p.rows_per_img;
@@ -640,7 +798,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     size_t prev_off = 0;
     uint32_t prev_nm = 0;
     uint32_t nq = 0;           // queued positions (wave-uniform)
-    uint32_t dense_nm = 0;     // != 0: the tile just computed has to be evaluated as a whole (its MCU count)
+    uint32_t nover = 0;        // entries of the overflow list
     uint32_t nq_total = 0;
     for (uint32_t tile = blockIdx.x, tilek = 0;; tile += gridDim.x, ++tilek) {
         const bool more = tile < p.ntiles;
@@ -649,16 +807,15 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
         const bool active = (uint32_t)grp < nm;
-        // MCU of this lane's group (groups beyond the image re-read the tile's first MCU; their pixels are never stored)
-        const size_t mcu = (size_t)trow * p.mcus_w + m0 + (active ? grp : 0);
-#ifdef KPEG_ABLATE_LOADS
-        const uint4 d0 = make_uint4(tile, tid, 0, 0), d1 = make_uint4(tid, 0, 0, 0), d2 = make_uint4(tile & 3, 0, 0, 0);
-        const float e0 = 0.001f * (float)(mcu & 7), e1 = 0.0f, e2 = 0.0f;
-#else
-        const uint4* src = reinterpret_cast<const uint4*>(p.coef) + mcu * 24 + u;
+        // MCU of this lane's group (groups beyond the image re-read the tile's first MCU; their pixels are never stored).
+        // Addresses are a scalar base (the tile's first MCU) plus a 32-bit lane offset: global_load with an SGPR base.
+        const size_t mcu0 = (size_t)trow * p.mcus_w + m0;
+        uint32_t lane_mcu = active ? (uint32_t)grp : 0u;
+        asm volatile("" : "+v"(lane_mcu));
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu0 * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
         const uint4 d0 = src[0], d1 = src[8], d2 = src[16];
-        const float e0 = p.ebound[mcu * 3], e1 = p.ebound[mcu * 3 + 1], e2 = p.ebound[mcu * 3 + 2];
-#endif
+        const float* eb = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(p.ebound + mcu0 * 3) + lane_mcu * 12u);
+        const float e0 = eb[0], e1 = eb[1], e2 = eb[2];
         const size_t cur_off = tile_offset(trow, m0);
         if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
         have_prev = true;
@@ -697,7 +854,8 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         // queued straight from this loop with ballot compaction (no atomics, no second pass).
         uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
         const uint32_t nq_tile = nq;
-        const uint32_t pos_lane = (uint32_t)grp | ((uint32_t)lane8 << 3) | (tilek << 9);
+        const uint32_t pos_lane = (uint32_t)grp | ((uint32_t)lane8 << 3) | (tilek << 12) | ((__float_as_uint(e0) >> 31) << 9) |
+                                  ((__float_as_uint(e1) >> 31) << 10) | ((__float_as_uint(e2) >> 31) << 11);
         const unsigned long long active_mask = __ballot(active);
         // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
         auto pixel_loop = [&](auto with_wide) {
@@ -736,7 +894,17 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 const unsigned long long bal = __builtin_amdgcn_fcmpf(key, 0.0f, 3 /* FCMP_OGE */) & active_mask;
                 if (bal) {
                     const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                    if (key >= 0.0f && active && slot < QUEUE_CAP) s_queue[slot] = pos_lane | ((uint32_t)i << 6);
+                    if (key >= 0.0f && active) {
+                        const uint32_t pw = pos_lane | ((uint32_t)i << 6);
+                        if (slot < QUEUE_CAP) {
+                            uint32_t* q = s_queue + slot * QUEUE_WORDS;
+                            q[0] = pw;
+                            q[1] = __float_as_uint(ry), q[2] = __float_as_uint(rb), q[3] = __float_as_uint(rr);
+                            q[4] = __float_as_uint(fy), q[5] = __float_as_uint(fb), q[6] = __float_as_uint(fr);
+                        } else {
+                            s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
+                        }
+                    }
                     nq += __popcll(bal);
                 }
 #else
@@ -755,27 +923,23 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             dst[2] = make_uint2(pk[4], pk[5]);
         }
         nq_total += nq - nq_tile;
-        if (nq > QUEUE_CAP) {
-            // more unsafe pixels than the queue takes (adversarial input, extreme coefficients): the tile's own
-            // entries are dropped and every pixel of the tile is evaluated in reference order once it is written out
-            nq_total += nm * 64u - (nq - nq_tile);
-            nq = nq_tile;
-            dense_nm = nm;
+        if (nq > QUEUE_CAP) {   // the rest went to the overflow list
+            nover = nq - QUEUE_CAP;
+            nq = QUEUE_CAP;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the next iteration writes this tile back before its own colour phase overwrites the LDS tile
         }
-        // Fix-ups are due: a pass's worth of queued pixels, a dense tile, or the end of this wavefront's tiles.  Few
-        // values of the tile loop are live here.  Every tile a queued position refers to must have been stored, and
-        // the stores performed, before the fix-ups overwrite bytes of theirs.
-        if (nq >= QUEUE_FLUSH || dense_nm || (!more && nq)) {   // wave-uniform
+        // Fix-ups are due: a pass's worth of queued pixels or the end of this wavefront's tiles.  Few
+        // values of the tile loop are live here.  Every tile a queued position refers to must have been stored before
+        // (run_fixups waits for the stores to be performed before it patches bytes of theirs).
+        if (nq >= QUEUE_FLUSH || (!more && nq)) {   // wave-uniform
             if (have_prev) write_back(prev_off, prev_nm);
             have_prev = false;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!p.skip_exact) run_fixups(nq, tilek, dense_nm);
+            if (!p.skip_exact) run_fixups(nq, nover, tilek);
             nq = 0;
-            dense_nm = 0;
+            nover = 0;
         }
         if (!more) break;
     }
