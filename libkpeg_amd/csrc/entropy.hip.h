@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                     const uint32_t Eb = ((__float_as_uint(E) + 1u) & ~1u) | ((tdc && !(Asum < 249.0f)) ? 1u : 0u);
                     const float Ef = __uint_as_float(Eb);
 #if KPEG_ABLATE_W != 3
-                    a.ebound[gb] = !(Asum < 31000.0f) ? __builtin_inff() : ((F & F_NONCORNER) ? Ef : -Ef);
+                    a.ebound[gb] = !(Asum < 4000.0f) ? __builtin_inff() : ((F & F_NONCORNER) ? Ef : -Ef);
 #else
                     if (E == 123.0f) a.ebound[gb] = E;
 #endif
@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     auto settle = [&](uint32_t blk, float A, int n, bool crn, int chroma) {
         const float E = n ? (0x1.004p-24f * A) * ((float)n + 14.5f) : 0.0f;
         const float Ef = __uint_as_float(((__float_as_uint(E) + 1u) & ~1u) | ((chroma && !(A < 249.0f)) ? 1u : 0u));
-        if (A < 31000.0f) a.ebound[blk] = crn ? -Ef : Ef;   // else the preset +inf stands
+        if (A < 4000.0f) a.ebound[blk] = crn ? -Ef : Ef;   // else the preset +inf stands
     };
     const uint32_t nown = min((uint32_t)OWN, nsub - i0);
     const bool tail = threadIdx.x == nown - 1 && (share.z & SH_OPEN);   // the workgroup's last lane leaves a block open

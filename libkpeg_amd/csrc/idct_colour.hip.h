@@ -196,19 +196,18 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
 #define KPEG_U 0x1.004p-24f   // 2^-24 (1 + 2^-10): covers the f32 rounding of A's own summation
 // chroma magnitude below which the f32 colour arithmetic is proven exact (DESIGN.md "colour")
 #define KPEG_CHROMA_LIM 250.0f
-#define KPEG_LUMA_LIM 32000.0f
 // |t - rint(t)| below this sends the G channel to the exact path (f32 error of t <= 3.7e-5)
 #define KPEG_G_DELTA 6.0e-5f
 
 // Range guards folded into the bound: every fast sample satisfies |v| <= A (1 + 2^-20).
-//   A >= KPEG_A_LIM (any component): the queue's int16 fields (|.| < 32000) could overflow: E = +inf, all the
-//       block's samples take the reference-order path.
+//   A >= KPEG_A_LIM (any component): beyond the range the colour arithmetic's rounding argument is checked for
+//       (|sample| <= 4100, tests/test_tables.py): E = +inf, all the block's samples take the reference-order path.
 //   A >= KPEG_A_LIM_CHROMA (chroma block): the samples may leave the range the f32 colour arithmetic is proven
 //       for (|.| < 250): the lowest mantissa bit of E is set (E is first rounded up to an even mantissa, so the
 //       bit never shrinks it) and K4 converts that MCU's pixels with the reference's double arithmetic in-lane.
 //       Saturated colour edges do this in photographs; dense noise does it everywhere.
 #define KPEG_A_LIM_CHROMA 249.0f
-#define KPEG_A_LIM 31000.0f
+#define KPEG_A_LIM 4000.0f
 // The sign bit carries one more fact about the block: set = every non-zero AC coefficient sits at
 // (0,1), (1,0) or (1,1).  Those blocks produce nearly all true ties (equal and opposite (0,1)/(1,0)
 // terms cancel on the diagonal), and their reference-order sum has at most four terms, which the
@@ -867,11 +866,16 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 const float fy = fabsf(vy - ry) + nthr0, fb = fabsf(vb - rb) + nthr1, fr = fabsf(vr - rr) + nthr2;
                 // colour from the three rounded samples (minus the level shift); dt = how far the G term's t is from
                 // an integer, as seen by the f32 arithmetic
-                const float yf = ry + 128.0f;
-                float R = yf + floorf(rr * 1.402f);
-                float B = yf + floorf(rb * 1.772f);
+                // v_cvt_pk_u8_f32 rounds to nearest-even and saturates.  All three channels are handed to it 0.499 below
+                // their value: floor(Y + k c) for R and B -- the fractions of 1.402 c and 1.772 c are multiples of 1/500 and
+                // 1/250, so value - 0.499 lies in (n - 0.5, n + 0.5) with 0.001 to spare on either side, more than the f32
+                // roundings of the two operations can move it for |Y| <= 4100, |c| <= 249 -- and the integer Y - ceil(t) for G
+                // (tests/test_tables.py checks every case).  No floor, no separate level-shift add.
+                const float yo = ry + 127.501f;
+                float R = __builtin_fmaf(rr, 1.402f, yo);
+                float B = __builtin_fmaf(rb, 1.772f, yo);
                 const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
-                float G = yf - ceilf(t);
+                float G = yo - ceilf(t);
                 // distance of t to the nearest integer, except that t == 0 (Cb = Cr = 128, exact in the
                 // reference too) must not count: non-zero |t| is >= 8e-6, so 1 - |t| * 2^17 <= 0 there
                 float dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));

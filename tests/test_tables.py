@@ -49,7 +49,7 @@ def test_kernel_error_constant_covers_the_derived_bound():
     # K2 writes the same bound formula as block_ebound()
     ent = open(os.path.join(CSRC, "entropy.hip.h")).read()
     assert "(0x1.004p-24f * Asum) * ((float)nnz + %sf)" % ("%.1f" % kk) in ent
-    assert "Asum < 249.0f" in ent and "Asum < 31000.0f" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM 31000.0f" in src
+    assert "Asum < 249.0f" in ent and "Asum < 4000.0f" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM 4000.0f" in src
     assert "(__float_as_uint(E) + 1u) & ~1u" in ent and "(__float_as_uint(E) + 1u) & ~1u" in src   # same flag encoding on both sides
     assert "#define KPEG_U 0x1.004p-24f" in src
 
@@ -90,3 +90,26 @@ def test_fast_path_error_bound_holds_empirically():
             else:
                 assert err == 0.0
     assert worst < 1.0, worst
+
+
+def test_colour_arithmetic_is_exact_over_its_whole_range():
+    """K4 hands v_cvt_pk_u8_f32 (round to nearest even, saturating) the values fma(Cr', 1.402f, Yo), fma(Cb', 1.772f, Yo)
+    and Yo - ceil(t) with Yo = rounded luma + 127.501f.  Every case the fast path admits (|chroma| <= 249 by
+    KPEG_A_LIM_CHROMA, |luma| <= 4000 by KPEG_A_LIM) must give the reference's clamp(floor(exact value)) (MCU.cpp:259-265
+    evaluates in double: exact unless the value is an integer, which happens only for chroma 0)."""
+    f32 = np.float32
+    ry = np.arange(-4100, 4101, dtype=np.float64)
+    yo = (ry + np.float64(f32(127.501))).astype(f32)   # the sum is exact in double: one f32 rounding
+    ch = np.arange(-249, 250, dtype=np.float64)
+
+    def cvt(x):
+        return np.clip(np.rint(x.astype(np.float64)), 0, 255).astype(np.int64)
+
+    for c, num, den in ((1.402, 701, 500), (1.772, 443, 250)):
+        arg = (ch[None, :] * np.float64(f32(c)) + yo[:, None].astype(np.float64)).astype(f32)   # exact in double, one rounding = fma
+        exact = np.array([(int(v) * num) // den for v in ch], dtype=np.int64)   # floor(ch * c), rational arithmetic
+        want = np.clip(ry[:, None].astype(np.int64) + 128 + exact[None, :], 0, 255)
+        assert np.array_equal(cvt(arg), want)
+    k = np.arange(-270, 271, dtype=np.float64)   # ceil(t)
+    arg = (yo[:, None].astype(np.float64) - k[None, :]).astype(f32)
+    assert np.array_equal(cvt(arg), np.clip(ry[:, None].astype(np.int64) + 128 - k[None, :].astype(np.int64), 0, 255))

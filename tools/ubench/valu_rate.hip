@@ -43,6 +43,26 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long lo
     if (WHICH == 16) { BODY("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD src0_sel:WORD_1") }
     if (WHICH == 17) { BODY("v_cndmask_b32 %0, %1, %2, vcc") }
     if (WHICH == 18) { BODY("v_cmp_eq_f32 vcc, %0, %1") }
+    if (WHICH == 19) { BODY("v_and_b32 %0, %0, %1") }
+    if (WHICH == 20) { BODY("v_lshlrev_b32 %0, 1, %1") }
+    if (WHICH == 21) { BODY("v_add_u32 %0, %0, %1") }
+    if (WHICH == 22) { BODY("v_sub_f32 %0, %0, %8") }
+    if (WHICH == 23) { BODY("v_add_f32_e64 %0, %8, |%1|") }
+    if (WHICH == 24) { BODY("v_fma_f32 %0, |%0|, %8, %1") }
+    if (WHICH == 25) { BODY("v_min_f32 %0, %0, %1") }
+    if (WHICH == 26) { BODY("v_fract_f32 %0, %1") }
+    if (WHICH == 27) { BODY("v_trunc_f32 %0, %1") }
+    if (WHICH == 28) { BODY("v_cvt_u32_f32 %0, %1") }
+    if (WHICH == 29) { BODY("v_alignbit_b32 %0, %0, %1, 31") }
+    if (WHICH == 30) { BODY("v_perm_b32 %0, %0, %1, %2") }
+    if (WHICH == 31) { BODY("v_mov_b32 %0, %1") }
+    if (WHICH == 34) { BODY("v_and_or_b32 %0, %0, %1, %2") }
+    if (WHICH == 35) { BODY("v_cmp_le_f32 vcc, 0, %0") }
+    if (WHICH == 36) { BODY("v_mad_u32_u24 %0, %0, %1, %2") }
+    if (WHICH == 37) { BODY("v_bfe_i32 %0, %1, 0, 16") }
+    if (WHICH == 38) { BODY("v_lshl_or_b32 %0, %0, 3, %1") }
+    if (WHICH == 39) { BODY("v_sub_f32_e64 %0, %8, |%1|") }
+    if (WHICH == 40) { BODY("v_max_f32_e64 %0, |%0|, %1") }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + b0.x + b1.y + b2.x + b3.y;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -81,8 +101,24 @@ void run(const char* name, int wavesPerSimd)
     hipFree(cyc);
 }
 
+__global__ void k_round(const float* in, unsigned* out, int n)
+{
+    int i = threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_cvt_pk_u8_f32(in[i], 0, 0);
+}
+
 int main()
 {
+    {
+        float h[16] = {0.25f, 0.5f, 0.75f, 0.999f, 1.5f, 2.5f, 3.5f, 254.5f, 254.999f, 255.5f, 300.f, -0.25f, -0.75f, -3.f, 127.5f, 128.5f};
+        float* d; unsigned* o; unsigned ho[16];
+        hipMalloc(&d, sizeof h); hipMalloc(&o, sizeof ho);
+        hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_round, dim3(1), dim3(64), 0, 0, d, o, 16);
+        hipMemcpy(ho, o, sizeof ho, hipMemcpyDeviceToHost);
+        for (int i = 0; i < 16; ++i) printf("cvt_pk_u8_f32(%g) = %u\n", h[i], ho[i]);
+    }
+
     for (int w : {1, 2, 4}) {
         run<0>("v_fma_f32", w);
         run<13>("v_fmac_f32", w);
@@ -103,6 +139,14 @@ int main()
         run<14>("v_max3_f32", w);
         run<17>("v_cndmask_b32", w);
         run<18>("v_cmp_eq_f32", w);
+        if (w == 4) {
+            run<19>("v_and_b32", w); run<20>("v_lshlrev_b32", w); run<21>("v_add_u32", w); run<22>("v_sub_f32", w);
+            run<23>("v_add_f32 |abs| e64", w); run<24>("v_fma_f32 |abs|", w); run<25>("v_min_f32", w); run<26>("v_fract_f32", w);
+            run<27>("v_trunc_f32", w); run<28>("v_cvt_u32_f32", w); run<29>("v_alignbit_b32", w); run<30>("v_perm_b32", w);
+            run<31>("v_mov_b32", w); run<34>("v_and_or_b32", w);
+            run<35>("v_cmp_le_f32 0", w); run<36>("v_mad_u32_u24", w); run<37>("v_bfe_i32", w); run<38>("v_lshl_or_b32", w);
+            run<39>("v_sub_f32 |abs| e64", w); run<40>("v_max_f32 |abs|", w);
+        }
         printf("\n");
     }
     return 0;
