@@ -19,6 +19,9 @@ HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # bit-exactness contract: no FMA contraction anywhere; FMAs are written explicitly
     "-ffp-contract=off",
+    # no SLP vectorisation: it turns pairs of f32 adds/muls/fmas into v_pk_* instructions, which issue at 2.7 cycles
+    # where the scalar forms issue at 1.7 (tools/ubench/valu_rate.hip), and pays v_mov/s_mov to line operands up
+    "-fno-slp-vectorize",
     "-Wall",
     "-Wno-unused-function",
 ]

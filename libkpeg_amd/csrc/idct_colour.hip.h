@@ -875,10 +875,16 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 float R = __builtin_fmaf(rr, 1.402f, yo);
                 float B = __builtin_fmaf(rb, 1.772f, yo);
                 const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
-                float G = yo - ceilf(t);
-                // distance of t to the nearest integer, except that t == 0 (Cb = Cr = 128, exact in the
-                // reference too) must not count: non-zero |t| is >= 8e-6, so 1 - |t| * 2^17 <= 0 there
-                float dt = fmaxf(fabsf(t - __builtin_rintf(t)), __builtin_fmaf(fabsf(t), -131072.0f, 1.0f));
+                const float tc = ceilf(t);
+                float G = yo - tc;
+                // G needs the reference's double arithmetic where t is within KPEG_G_DELTA of a non-zero integer
+                // (t == 0, i.e. Cb = Cr = 128, is exact in the reference too; non-zero |t| is >= 8e-6, so
+                // |t| * 2^17 >= 1 there).  Both conditions and the three sample keys are combined as sign bits with
+                // and/or (1.7-cycle instructions; max/max3/rndne issue at 2.7): the sign of `safe` is set iff nothing
+                // about this pixel is unsafe.
+                const float ka = fabsf((tc - t) - 0.5f) - (0.5f - KPEG_G_DELTA);                // >= 0: within DELTA of an integer
+                const float kb = __builtin_fmaf(fabsf(t), 131072.0f, KPEG_G_DELTA - 1.0f);      // >= 0: t != 0
+                uint32_t kg = __float_as_uint(ka) | __float_as_uint(kb);                         // sign clear: G is unsafe
                 if (decltype(with_wide)::value) {
                     if (wide) {
                         // out of the f32 colour arithmetic's range: the reference's own double arithmetic on the rounded samples
@@ -886,19 +892,19 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                         R = (float)(px & 0xFF);
                         G = (float)((px >> 8) & 0xFF);
                         B = (float)(px >> 16);
-                        dt = 1.0f;   // G is exact here
+                        kg = 0x80000000u;   // G is exact here
                     }
                 }
-                const float key = fmaxf(fmaxf(fy, fmaxf(fb, fr)), KPEG_G_DELTA - dt);
+                const uint32_t safe = __float_as_uint(fy) & __float_as_uint(fb) & __float_as_uint(fr) & kg;
                 pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
                 pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
                 pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
 #ifndef KPEG_ABLATE_PUSH
                 // one wave-uniform test per pixel column: nobody flagged -> next column
-                const unsigned long long bal = __builtin_amdgcn_fcmpf(key, 0.0f, 3 /* FCMP_OGE */) & active_mask;
+                const unsigned long long bal = __ballot((int)safe >= 0) & active_mask;
                 if (bal) {
                     const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                    if (key >= 0.0f && active) {
+                    if ((int)safe >= 0 && active) {
                         const uint32_t pw = pos_lane | ((uint32_t)i << 6);
                         if (slot < QUEUE_CAP) {
                             uint32_t* q = s_queue + slot * QUEUE_WORDS;
@@ -912,7 +918,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                     nq += __popcll(bal);
                 }
 #else
-                (void)key;
+                (void)safe;
 #endif
             }
         };

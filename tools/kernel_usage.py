@@ -3,7 +3,7 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "libkpeg_amd", "csrc", "kpeg_hip.hip")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
        "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_kpeg_usage.so", src]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None

@@ -7,7 +7,7 @@ rm -rf build/ablate; mkdir -p build/ablate
 n=0
 for spec in "$@"; do
   name=${spec%%=*}; defs=${spec#*=}; [ "$defs" = "$spec" ] && defs=""
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude $defs \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-slp-vectorize -Iinclude $defs \
       -o build/ablate/libkpeg_hip_$name.so libkpeg_amd/csrc/kpeg_hip.hip 2>build/ablate/$name.log &
   n=$((n+1)); [ $((n % 6)) = 0 ] && wait
 done
