@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--restart-stripe", action="store_true",
                     help="N=1 only: decode the workload the N>1 ranks get (restart interval = one MCU row, DRI extension) instead of "
                          "the reference-compatible stream; tells what part of the N>1 per-rank time the restart machinery costs")
+    ap.add_argument("--cold", action="store_true",
+                    help="with --idct-only: overwrite a 1 GiB scratch buffer before every step, so that K4 finds neither its "
+                         "coefficients nor its output lines in L2 / Infinity Cache (the kernel's own events exclude the fill)")
     ap.add_argument("--side-figures", action="store_true",
                     help="also report SURVEY 8(d)'s side figures: measured device-copy ceiling and the dense q95 noise stress input "
                          "(off by default so that a rocprofv3 summary of the default command holds the headline workload only)")
@@ -224,8 +227,12 @@ def main():
     d_coef = torch.empty(mw * mh * 192, dtype=torch.int16, device="cuda") if args.idct_only else None
     torch.cuda.synchronize()
 
+    scratch = torch.empty(1 << 30, dtype=torch.uint8, device="cuda") if (args.idct_only and args.cold) else None
+
     def step():
         if args.idct_only:
+            if scratch is not None:
+                scratch.fill_(7)
             ctx.idct_colour_dev(frame1, d_coef.data_ptr(), d_rgb.data_ptr())
         else:
             ctx.decode_stripe_dev(frame, d_scan.data_ptr(), d_scan.numel(), first_row, rows, d_rgb.data_ptr())

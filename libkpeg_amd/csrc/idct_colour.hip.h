@@ -629,8 +629,11 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
 #ifdef KPEG_ABLATE_STORES
                 if (p.ntiles == 1) *reinterpret_cast<uint4*>(base + oA) = *reinterpret_cast<const uint4*>(s_tile + wb_lds);
 #else
-                *reinterpret_cast<uint4*>(base + oA) = *reinterpret_cast<const uint4*>(s_tile + wb_lds);
-                *reinterpret_cast<uint4*>(base + (size_t)4 * p.pitch + oA) = *reinterpret_cast<const uint4*>(s_tile + wb_lds + 4 * TILE_ROW_STRIDE);
+                // nontemporal: the pixels are not read again here, and written the ordinary way they push the
+                // coefficients K1/K2 have just produced out of the Infinity Cache ahead of this kernel's own loads
+                // (K4 inside the decode: 0.084 -> 0.073 ms)
+                __builtin_nontemporal_store(*reinterpret_cast<const uint4v*>(s_tile + wb_lds), reinterpret_cast<uint4v*>(base + oA));
+                __builtin_nontemporal_store(*reinterpret_cast<const uint4v*>(s_tile + wb_lds + 4 * TILE_ROW_STRIDE), reinterpret_cast<uint4v*>(base + (size_t)4 * p.pitch + oA));
 #endif
             }
         } else {
