@@ -333,7 +333,7 @@ def main():
         torch.cuda.synchronize()
         sms = (time.perf_counter() - s0) / 20 * 1e3
         ctx.sync()
-        stress = {"workload": "%dx%d dense uniform noise, q95 (every coefficient non-zero; re-synchronises over thousands of bits: K1 is 95 % of the time)" % (sw, sh),
+        stress = {"workload": "%dx%d dense uniform noise, q95 (every coefficient non-zero; re-synchronises over thousands of bits: K1 is 95 %% of the time)" % (sw, sh),
                   "scan_bytes": int(sd_scan.numel()), "ms_per_step": round(sms, 4), "value": round(sw * sh / (sms * 1e-3) / 1e6, 2),
                   "unit": "Mpixels/s"}
 

@@ -43,6 +43,13 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long lo
     if (WHICH == 16) { BODY("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD src0_sel:WORD_1") }
     if (WHICH == 17) { BODY("v_cndmask_b32 %0, %1, %2, vcc") }
     if (WHICH == 18) { BODY("v_cmp_eq_f32 vcc, %0, %1") }
+    if (WHICH == 42) { BODY("v_cndmask_b32_e64 %0, %1, %2, s[10:11]") }
+    if (WHICH == 43) { BODY("v_cndmask_b32 %0, %1, %2, vcc\n\tv_cndmask_b32 %1, %2, %3, vcc\n\tv_cndmask_b32 %2, %3, %0, vcc\n\tv_cndmask_b32 %3, %0, %1, vcc") }
+    if (WHICH == 44) { BODY("v_bfi_b32 %0, %1, %2, %3") }
+    if (WHICH == 45) { BODY("v_cndmask_b32_e64 %0, 0, 1, s[10:11]") }
+    if (WHICH == 46) { BODY("v_ashrrev_i32 %0, 31, %1") }
+    if (WHICH == 47) { BODY("v_min_u32 %0, %0, %1") }
+    if (WHICH == 48) { BODY("v_cndmask_b32_e64 %0, %1, %2, s[10:11]\n\tv_add_u32 %1, %1, %3") }
     if (WHICH == 19) { BODY("v_and_b32 %0, %0, %1") }
     if (WHICH == 20) { BODY("v_lshlrev_b32 %0, 1, %1") }
     if (WHICH == 21) { BODY("v_add_u32 %0, %0, %1") }
@@ -146,6 +153,8 @@ int main()
             run<31>("v_mov_b32", w); run<34>("v_and_or_b32", w);
             run<35>("v_cmp_le_f32 0", w); run<36>("v_mad_u32_u24", w); run<37>("v_bfe_i32", w); run<38>("v_lshl_or_b32", w);
             run<39>("v_sub_f32 |abs| e64", w); run<40>("v_max_f32 |abs|", w);
+            run<42>("v_cndmask_b32_e64 sgpr", w); run<43>("4x v_cndmask vcc rotating regs (per 4)", w); run<44>("v_bfi_b32", w);
+            run<45>("v_cndmask_b32_e64 0,1", w); run<46>("v_ashrrev_i32", w); run<47>("v_min_u32", w); run<48>("cndmask+add pair (per 2)", w);
         }
         printf("\n");
     }
