@@ -646,6 +646,8 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         }
     };
 
+    uint32_t dbg_count = 0;   // experiments (KPEG_COUNT_*): reported in place of the unsafe-pixel count
+
     // Fix-up passes.  A queue entry is a pixel of one of this wavefront's tiles:
     //   word 0: [2:0] MCU within the tile, [5:3] pixel row, [8:6] pixel column, [11:9] component blocks that are
     //           corner-only (the sign of their bound), [31:12] the tile's sequence number k (tile = blockIdx.x + k * gridDim.x);
@@ -706,8 +708,20 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 mm &= mm - 1;
             };
             const int16_t* c16 = p.coef;
-            constexpr int BATCH = 12;
+#ifndef KPEG_COOP_BATCH
+#define KPEG_COOP_BATCH 4
+#endif
+            constexpr int BATCH = KPEG_COOP_BATCH;
             const bool many = __popcll(g0) + __popcll(g1) + __popcll(g2) > BATCH;   // wave-uniform
+#if defined(KPEG_COUNT_COOP)
+            dbg_count += __popcll(g0) + __popcll(g1) + __popcll(g2);
+#elif defined(KPEG_COUNT_MANY)
+            dbg_count += many ? 1u : 0u;
+#elif defined(KPEG_COUNT_FLUSH)
+            dbg_count += 1u;
+#elif defined(KPEG_COUNT_CORNER)
+            dbg_count += __popcll(__ballot(cn0)) + __popcll(__ballot(cn1)) + __popcll(__ballot(cn2));
+#endif
             // a batch of those: one coalesced 128-byte load per sample, all in flight together with the corner words
             // (one memory latency per pass -- at the end of a wavefront's life nothing hides it)
             int cf[BATCH];
@@ -912,8 +926,10 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                         if (slot < QUEUE_CAP) {
                             uint32_t* q = s_queue + slot * QUEUE_WORDS;
                             q[0] = pw;
+#ifndef KPEG_PUSH_POS_ONLY
                             q[1] = __float_as_uint(ry), q[2] = __float_as_uint(rb), q[3] = __float_as_uint(rr);
                             q[4] = __float_as_uint(fy), q[5] = __float_as_uint(fb), q[6] = __float_as_uint(fr);
+#endif
                         } else {
                             s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
                         }
@@ -959,6 +975,11 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     if (have_prev) write_back(prev_off, prev_nm);
     // one fire-and-forget add per wavefront, spread over 256 words (a single hot word serialises in L2)
     uint32_t dep = 0;
+#if defined(KPEG_COUNT_COOP) || defined(KPEG_COUNT_MANY) || defined(KPEG_COUNT_FLUSH) || defined(KPEG_COUNT_CORNER)
+    nq_total = dbg_count;
+#else
+    (void)dbg_count;
+#endif
     if (tid == 0 && nq_total && p.stats) dep = atomicAdd(&p.stats[blockIdx.x & 255], nq_total);
     status_epilogue(p.status, p.h_status, gridDim.x, p.keep_status, dep);
 }
