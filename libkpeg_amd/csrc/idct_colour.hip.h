@@ -10,14 +10,17 @@
 // cannot be reproduced by a fast transform.  The kernel therefore computes
 //   (1) a fast separable f32 IDCT whose distance to the reference's float result is
 //       bounded rigorously per block (tools/idct_bound.py derives the constant), and
-//   (2) only where the fast value lies within that bound of a rounding boundary (or an
-//       operand leaves the range the fast colour arithmetic is proven for), the
-//       reference-order evaluation itself, done cooperatively by one wavefront per pixel.
+//   (2) only where the fast value lies within that bound of a rounding boundary (or the G
+//       term is too close to an integer for the f32 colour arithmetic), the reference-order
+//       evaluation itself: such pixels are queued in the tile loop and fixed up in passes,
+//       after their tile has been stored (see k_idct_colour_fast).
 // Blocks with no AC coefficient are exact in (1) by construction.
 //
-// Mapping (no MFMA: this is HBM-bound byte/short work).
-//   * 8 lanes per MCU, 8 MCUs per wavefront, 32 MCUs (256x8 pixels) per 256-thread
-//     workgroup iteration; persistent grid-stride loop over tiles.
+// Mapping (no MFMA: byte/short work, not a dense contraction; the kernel is bound by VALU issue,
+// and on gfx950 only add/sub/mul/fma/and/or/mov issue at 1.7 cycles, everything else at 2.7:
+// tools/ubench/valu_rate.hip).
+//   * one wavefront per workgroup, 8 lanes per MCU, 8 MCUs (64x8 pixels) per tile; the grid is the
+//     resident wavefronts, each walks tiles blockIdx.x, + gridDim.x, ...
 //   * lane j of an 8-lane group loads one 16-byte row of each component block
 //     (rows 0,2,4,6 on lanes 0-3, rows 1,3,5,7 on lanes 4-7): a wavefront's three
 //     global_load_dwordx4 cover 8 MCUs x 384 B = 3 KiB of contiguous coefficients.
@@ -194,8 +197,6 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
 // for caller-supplied coefficients) and read here as a 4-byte sidecar per block.
 #define KPEG_KAPPA 14.5f      // tools/idct_bound.py prints 14.444
 #define KPEG_U 0x1.004p-24f   // 2^-24 (1 + 2^-10): covers the f32 rounding of A's own summation
-// chroma magnitude below which the f32 colour arithmetic is proven exact (DESIGN.md "colour")
-#define KPEG_CHROMA_LIM 250.0f
 // |t - rint(t)| below this sends the G channel to the exact path (f32 error of t <= 3.7e-5)
 #define KPEG_G_DELTA 6.0e-5f
 
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
 // The sign bit carries one more fact about the block: set = every non-zero AC coefficient sits at
 // (0,1), (1,0) or (1,1).  Those blocks produce nearly all true ties (equal and opposite (0,1)/(1,0)
 // terms cancel on the diagonal), and their reference-order sum has at most four terms, which the
-// lane that found the tie evaluates itself (exact_corner) instead of queueing the pixel.
+// lane that holds the pixel's queue entry evaluates itself in the fix-up pass (exact_corner).
 __device__ __forceinline__ float block_ebound(float A, int nnz_ac, bool chroma, bool corner_only)
 {
     if (!(A < KPEG_A_LIM)) return __builtin_inff();
