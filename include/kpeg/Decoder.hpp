@@ -65,6 +65,9 @@ namespace kpeg
             /// The entropy-coded segment as scanImageData collected it (still byte-stuffed).
             const std::vector<UInt8>& scanData() const { return scan_; }
             Image& image() { return image_; }
+            /// After a parse-only decodeImageFile(): the stream is one the GPU path takes (two quantisation tables, four
+            /// Huffman tables, exactly one non-empty scan, dimensions multiples of 8) -- the conditions decodeScanData() checks.
+            bool decodable() const;
             /// Parse an in-memory file instead of open().
             void openMemory( const UInt8* data, std::size_t size, const std::string& name );
 

@@ -397,6 +397,13 @@ namespace kpeg
         return true;
     }
 
+    bool JPEGDecoder::decodable() const
+    {
+        kpeg_frame f;
+        const unsigned w = image_.getWidth(), h = image_.getHeight();
+        return !scan_.empty() && sosCount_ == 1 && frameInfo( &f ) && w != 0 && h != 0 && !( w & 7 ) && !( h & 7 );
+    }
+
     JPEGDecoder::ResultCode JPEGDecoder::decodeScanData()
     {
         if ( scan_.empty() )

@@ -4,13 +4,17 @@
 // must end in ".jpg" (isValidFilename), the PPM lands next to the input, kpeg.log is created
 // in the working directory.  The encode direction (`kpeg in.ppm out.jpg`) belongs to the
 // reference's unfinished encoder and is out of scope here; it reports that and exits.
-// Extension: `--allow-dri` accepts streams with restart markers.
+// Extensions: `--allow-dri` accepts streams with restart markers; `--batch` takes any number of files and
+// directories and decodes files of identical geometry and tables together (kpeg::decodeFiles).
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <string>
 
+#include <vector>
+
+#include "Batch.hpp"
 #include "Decoder.hpp"
 #include "Logger.hpp"
 #include "Utility.hpp"
@@ -23,6 +27,7 @@ static void printHelp()
     std::cout << "Help\n" << std::endl;
     std::cout << "<filename.jpg>                  : Decompress a JPEG image to a PPM image" << std::endl;
     std::cout << "--allow-dri <filename.jpg>      : same, accepting restart markers (extension)" << std::endl;
+    std::cout << "--batch [--allow-dri] <files and directories...> : Decompress many JPEG images (extension)" << std::endl;
     std::cout << "-h                              : Print this help message and exit" << std::endl;
 }
 
@@ -63,6 +68,23 @@ int main( int argc, char** argv )
         {
             printHelp();
             return EXIT_SUCCESS;
+        }
+        if ( argc >= 3 && std::string( argv[1] ) == "--batch" )
+        {
+            bool allowDRI = false;
+            std::vector<std::string> names;
+            for ( int i = 2; i < argc; ++i )
+            {
+                if ( std::string( argv[i] ) == "--allow-dri" )
+                    allowDRI = true;
+                else
+                    names.push_back( argv[i] );
+            }
+            kpeg::Logger::get().setLevel( kpeg::Logger::Level::ERROR );   // one INFO line per marker and file is too much here
+            const kpeg::BatchResult r = kpeg::decodeFiles( names, allowDRI );
+            std::cout << "kpeg --batch: " << r.written << " PPM written, " << r.rejected << " rejected, " << r.failed
+                      << " failed, " << r.groups << " group(s)" << std::endl;
+            return r.failed ? EXIT_FAILURE : EXIT_SUCCESS;
         }
         if ( argc == 2 )
             return decodeJPEG( argv[1], false );

@@ -323,6 +323,43 @@ def test_cli_writes_the_reference_ppm(tmp_path):
     assert os.path.exists(tmp_path / "rej_dri.ppm")
 
 
+def test_cli_batch_front_end(tmp_path):
+    """`kpeg --batch <dir> <file>...` (extension): files of identical geometry and tables go through the
+    fused batch path together, the others alone; every PPM is what the single-file front end / the reference writes; a
+    corrupt stream inside a group costs only its own PPM; names and streams the single-file front end rejects are skipped."""
+    import os, shutil, subprocess
+    import libkpeg_amd as K
+    d = tmp_path / "in"
+    d.mkdir()
+    want = {}
+    # five images of one geometry and quality (one group), two others
+    for i in range(5):
+        data = T.synth_jpeg(160, 96, seed=100 + i, quality=75)
+        (d / ("a%d.jpg" % i)).write_bytes(data)
+        want["a%d" % i] = T.ppm_bytes(T.oracle_decode(data)[1])
+    for name, (w, h, q) in {"b0": (64, 64, 50), "b1": (200, 40, 90)}.items():
+        data = T.synth_jpeg(w, h, seed=7, quality=q)
+        (d / (name + ".jpg")).write_bytes(data)
+        want[name] = T.ppm_bytes(T.oracle_decode(data)[1])
+    # same geometry and tables as the group, but the entropy-coded data is garbage: fails alone
+    good = T.synth_jpeg(160, 96, seed=100, quality=75)
+    p = T.oracle_parse(good)
+    cut = good.find(p.scan[:16])
+    (d / "a9_corrupt.jpg").write_bytes(good[:cut] + bytes([0xFF, 0x00] * 40) + b"\xff\xd9")
+    # rejected by the parser (restart markers without --allow-dri), a name that does not end in .jpg, a golden file given by name
+    shutil.copy(os.path.join(T.GOLDEN, "rej_dri.jpg"), d / "rej_dri.jpg")
+    (d / "note.txt").write_text("not an image")
+    extra = tmp_path / "synth_64x64_q75.jpg"
+    shutil.copy(os.path.join(T.GOLDEN, "synth_64x64_q75.jpg"), extra)
+    out = subprocess.run([K.CLI, "--batch", str(d), str(extra)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert "8 PPM written" in out.stdout and "1 rejected" in out.stdout and "1 failed" in out.stdout, out.stdout[-800:] + out.stderr[-400:]
+    assert out.returncode != 0   # a failure is reported
+    for name, ppm in want.items():
+        assert open(d / (name + ".ppm"), "rb").read() == ppm, name
+    assert open(tmp_path / "synth_64x64_q75.ppm", "rb").read() == open(os.path.join(T.GOLDEN, "synth_64x64_q75.ppm"), "rb").read()
+    assert not os.path.exists(d / "a9_corrupt.ppm") and not os.path.exists(d / "rej_dri.ppm") and not os.path.exists(d / "note.ppm")
+
+
 def test_full_size_8k_properties(ctx):
     """BASELINE's full size (7680x4320): too slow for the scalar oracle in a unit test budget beyond one
     pass, so check it once against the multi-threaded oracle and by a checksum of row checksums."""
