@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             };
             const int16_t* c16 = p.coef;
 #ifndef KPEG_COOP_BATCH
-#define KPEG_COOP_BATCH 4
+#define KPEG_COOP_BATCH 2
 #endif
             constexpr int BATCH = KPEG_COOP_BATCH;
             const bool many = __popcll(g0) + __popcll(g1) + __popcll(g2) > BATCH;   // wave-uniform
