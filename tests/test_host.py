@@ -129,3 +129,21 @@ def test_is_valid_filename_quirks(K):
     assert ok("a.jpg") and ok("dir/x.y.jpg")
     assert not ok("a.jpeg")          # rejected by the reference's length test (Utility.hpp:23-37)
     assert not ok("a.jpg.bak") and not ok("a.png") and not ok("jpg")
+
+
+def test_batch_front_end_without_a_gpu_fails_loudly(K, tmp_path):
+    """`kpeg --batch` parses on the host and decodes on the GPU only: without a gfx950 device every accepted file is
+    reported as failed (there is no CPU decode path), rejected files as rejected, nothing is written, the exit code is non-zero."""
+    import shutil, subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_decode.py covers the batch front end")
+    d = tmp_path / "in"
+    d.mkdir()
+    shutil.copy(os.path.join(T.GOLDEN, "synth_64x64_q75.jpg"), d / "a.jpg")
+    shutil.copy(os.path.join(T.GOLDEN, "rej_dri.jpg"), d / "rej_dri.jpg")
+    (d / "note.txt").write_text("not an image")
+    out = subprocess.run([K.CLI, "--batch", str(d)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert "0 PPM written, 1 rejected, 1 failed" in out.stdout, out.stdout[-600:]
+    assert out.returncode != 0
+    assert not os.path.exists(d / "a.ppm")
