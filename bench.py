@@ -61,6 +61,18 @@ def synth_jpeg(w, h, y0=0, restart_interval=0, seed=SEED, quality=QUALITY, sigma
     return buf[:n].tobytes()
 
 
+def pinned_rgb_sha(w, h, world, rank, restart_stripe):
+    """SHA-256 of the raw RGB bytes libKPEG's own decoder produces for this rank's part of the workload, if pinned."""
+    mf = os.path.join(ROOT, "tests", "golden", "manifest_large.json")
+    if not os.path.exists(mf):
+        return None
+    m = json.load(open(mf))
+    if world == 1 and not restart_stripe:
+        g = m.get("synth", {}).get("%dx%d_seed%d" % (w, h, SEED))
+        return g["rgb_sha256"] if g and (g["quality"], g["sigma"]) == (QUALITY, SIGMA) else None
+    return None
+
+
 def cpu_baseline(sample_w=3840, sample_h=2160):
     """Reference CPU decoder on a bounded crop (top-left sample_w x sample_h of the 8K field)."""
     data = synth_jpeg(sample_w, sample_h)
@@ -263,7 +275,18 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ctx.sync()  # deferred device status of the last step (raises on a corrupt stream)
+    ctx.sync()  # deferred device status of every step enqueued above (the error word is sticky until this sync)
+    # ---- the pixels the timed loop produced, against libKPEG's own decoder -------------------------------------
+    # tests/golden/manifest_large.json holds SHA-256s of the reference's output on exactly these synthetic inputs
+    # (tests/golden/make_golden_large.py, build container); None = this workload has no pinned hash
+    verified = None
+    if not args.idct_only and args.idct_mode == 0:
+        want_sha = pinned_rgb_sha(W, H, world, rank, args.restart_stripe)
+        if want_sha is not None:
+            import hashlib
+            verified = hashlib.sha256(d_rgb.cpu().numpy().tobytes()).hexdigest() == want_sha
+            if not verified:
+                raise SystemExit("bench.py: rank %d decoded pixels that differ from the reference's (SHA-256 mismatch)" % rank)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -396,6 +419,7 @@ def main():
                            "no restart markers, full on-device Huffman + IDCT" if world == 1 and not args.restart_stripe else
                            "restart interval = 1 MCU row, %d row stripes of %d rows, one per GPU" % (world, H)),
                        "scan_bytes_per_gpu": int(d_scan.numel()), "pixels_per_step": pixels_per_step},
+            "verified": verified,   # the timed loop's output == the reference decoder's pixels (SHA-256), None = not pinned
             "roofline": roof,
             "kernels_ms": {k: round(v, 5) for k, v in tm.items() if k.endswith("_ms")},
             "sync_passes": tm.get("sync_rounds"), "exact_pixels_per_image": tm.get("exact_pixels"),

@@ -79,6 +79,9 @@ typedef struct kpeg_hip_timings {
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
 int kpeg_hip_abi_version(void);
+/* Hash of the kernel sources and compiler flags this library was built from; libkpeg_amd/build.py rebuilds the
+ * library when it differs from the hash of the sources in the tree (a stale binary must not reach the GPU). */
+const char* kpeg_hip_build_hash(void);
 int kpeg_hip_create(kpeg_hip_ctx** ctx, int device);
 void kpeg_hip_destroy(kpeg_hip_ctx* ctx);
 const char* kpeg_hip_strerror(int code);

@@ -42,6 +42,9 @@ int kpeg_host_huffman_contains(const uint8_t counts[16], const uint8_t* symbols,
 int kpeg_host_bitstring_to_value(const char* bits);
 int kpeg_host_value_to_bitstring(int value, char* out, size_t cap);
 
+/* Hash of the host sources this library was built from (libkpeg_amd/build.py rebuilds on a mismatch). */
+const char* kpeg_host_build_hash(void);
+
 /* kpeg::isValidFilename (include/Utility.hpp:16-38). */
 int kpeg_host_is_valid_filename(const char* name);
 

@@ -16,6 +16,7 @@ HIP_LIB = os.environ.get("KPEG_HIP_LIB") or os.path.join(_HERE, "libkpeg_hip.so"
 HOST_LIB = os.path.join(_HERE, "libkpeg.so")
 CLI = os.path.join(_HERE, "kpeg")
 
+ABI_VERSION = 1
 OK = 0
 E_ARG, E_DEVICE, E_TABLES, E_STREAM, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
@@ -51,7 +52,7 @@ class Timings(ctypes.Structure):
 
 
 EXPORTS = [
-    "kpeg_hip_abi_version", "kpeg_hip_create", "kpeg_hip_destroy", "kpeg_hip_strerror", "kpeg_hip_last_error",
+    "kpeg_hip_abi_version", "kpeg_hip_build_hash", "kpeg_hip_create", "kpeg_hip_destroy", "kpeg_hip_strerror", "kpeg_hip_last_error",
     "kpeg_hip_set_stream", "kpeg_hip_sync", "kpeg_hip_set_profiling", "kpeg_hip_get_timings",
     "kpeg_hip_idct_colour", "kpeg_hip_decode_scan", "kpeg_hip_decode_batch", "kpeg_hip_decode_batch_dev",
     "kpeg_hip_idct_colour_dev", "kpeg_hip_decode_scan_dev", "kpeg_hip_decode_stripe_dev",
@@ -79,6 +80,7 @@ def load_hip():
     vp, c_int, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     FP = ctypes.POINTER(Frame)
     L.kpeg_hip_abi_version.restype = c_int
+    L.kpeg_hip_build_hash.restype = ctypes.c_char_p
     L.kpeg_hip_create.argtypes = [ctypes.POINTER(vp), c_int]
     L.kpeg_hip_destroy.argtypes = [vp]
     L.kpeg_hip_destroy.restype = None

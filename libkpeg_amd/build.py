@@ -27,13 +27,49 @@ HIP_FLAGS = [
 ]
 
 
-def _newer(target, sources):
+def source_hash(sources, flags):
+    """SHA-256 over the contents of `sources` (by base name, sorted) and the compiler flags."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(sources, key=os.path.basename):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+        h.update(b"\0")
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()[:32]
+
+
+def stamped_hash(target):
+    """The source hash a binary was built from (it carries the string KPEG_SRC_HASH=<hex>), or None."""
     if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+        return None
+    blob = open(target, "rb").read()
+    i = blob.find(b"KPEG_SRC_HASH=")
+    if i < 0:
+        return None
+    return blob[i + 14:i + 14 + 32].decode("ascii", "replace")
 
 
+def _stale(target, want):
+    """Rebuild unless the binary exists and was built from exactly these sources and flags: a git-ignored .so
+    left over from other sources must never travel to the GPU box (modification times say nothing after a checkout)."""
+    return stamped_hash(target) != want
+
+
+def hip_sources():
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(ROOT, "include", "kpeg_hip.h"))
+    return srcs
+
+
+def host_sources():
+    host_dir = os.path.join(CSRC, "host")
+    srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp")]
+    hdrs = [os.path.join(ROOT, "include", "kpeg", f) for f in os.listdir(os.path.join(ROOT, "include", "kpeg"))]
+    return srcs + hdrs + [os.path.join(ROOT, "include", "kpeg_host.h"), os.path.join(ROOT, "include", "kpeg_hip.h")]
+
+
+HOST_FLAGS = ["-O2", "-std=c++14", "-Wall"]
 STRESS_DEFS = ["-DKPEG_SUBSEQ_BITS=64", "-DKPEG_SYNC_WG=128", "-DKPEG_WARM_BITS=64", "-DKPEG_POOL_SUBS=2"]
 
 
@@ -44,17 +80,18 @@ def _run(cmd, cwd=None):
 
 def build_hip(force=False):
     out = os.path.join(PKG, "libkpeg_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(ROOT, "include", "kpeg_hip.h"))
-    if not force and not _newer(out, srcs):
+    stress = os.path.join(PKG, "libkpeg_hip_stress.so")
+    h = source_hash(hip_sources(), HIP_FLAGS + STRESS_DEFS)
+    if not force and not _stale(out, h) and not _stale(stress, h):
         return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    _run([hipcc] + HIP_FLAGS + ["-o", out, os.path.join(CSRC, "kpeg_hip.hip")])
+    stamp = ['-DKPEG_SRC_HASH="%s"' % h]
+    _run([hipcc] + HIP_FLAGS + stamp + ["-o", out, os.path.join(CSRC, "kpeg_hip.hip")])
     # test-only twin with tiny K1/K2 workgroups and a 64-bit warm-up: real streams then need the boundary
     # passes and the chained pass that the product geometry almost never reaches; and a pool of two
     # second-level Huffman tables, so that the Annex-K tables overflow it and long codes take the
     # canonical-search fallback (tests/test_gpu_decode.py)
-    _run([hipcc] + HIP_FLAGS + STRESS_DEFS + ["-o", os.path.join(PKG, "libkpeg_hip_stress.so"), os.path.join(CSRC, "kpeg_hip.hip")])
+    _run([hipcc] + HIP_FLAGS + stamp + STRESS_DEFS + ["-o", stress, os.path.join(CSRC, "kpeg_hip.hip")])
     return out
 
 
@@ -66,15 +103,16 @@ def build_host(force=False):
     out = os.path.join(PKG, "libkpeg.so")
     cli = os.path.join(PKG, "kpeg")
     srcs = [os.path.join(host_dir, f) for f in sorted(os.listdir(host_dir)) if f.endswith(".cpp") and f != "main.cpp"]
-    hdrs = [os.path.join(ROOT, "include", "kpeg", f) for f in os.listdir(os.path.join(ROOT, "include", "kpeg"))]
-    if force or _newer(out, srcs + hdrs):
-        _run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"),
+    h = source_hash(host_sources(), HOST_FLAGS)
+    stamp = ['-DKPEG_SRC_HASH="%s"' % h]
+    if force or _stale(out, h):
+        _run(["g++"] + HOST_FLAGS + stamp + ["-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
               "-I" + os.path.join(ROOT, "include", "kpeg"), "-o", out] + srcs +
-             ["-L" + PKG, "-lkpeg_hip", "-Wl,-rpath,$ORIGIN"])
+             ["-L" + PKG, "-lkpeg_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     main = os.path.join(host_dir, "main.cpp")
-    if os.path.exists(main) and (force or _newer(cli, [main, out])):
-        _run(["g++", "-O2", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"),
-              "-I" + os.path.join(ROOT, "include", "kpeg"), "-o", cli, main, "-L" + PKG, "-lkpeg", "-lkpeg_hip",
+    if os.path.exists(main) and (force or _stale(cli, h)):
+        _run(["g++"] + HOST_FLAGS + stamp + ["-I" + os.path.join(ROOT, "include"),
+              "-I" + os.path.join(ROOT, "include", "kpeg"), "-o", cli, main, "-L" + PKG, "-lkpeg", "-lkpeg_hip", "-lpthread",
               "-Wl,-rpath,$ORIGIN"])
     return out
 

@@ -198,6 +198,34 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t total_blocks;
     uint32_t ticket;   // workgroups that have finished the chained pass
     uint32_t k0_slot[64], k0_top;   // K0's two-level ticket (restart segments: the last workgroup to finish sets the segments up)
+    uint32_t k1_order;   // K1's chained pass: logical workgroup index = the order in which workgroups start (K0 clears it)
+};
+
+// Waits between workgroups never rest on the order in which the hardware dispatches blockIdx (HIP promises none):
+//  * K0's decoupled look-back waits a short while for a predecessor's published aggregate and then computes that
+//    aggregate ITSELF from the predecessor's input bytes (look-back with fallback): no wait can last, whatever runs
+//    or does not run beside this workgroup;
+//  * K1's chained pass (a predecessor's result depends on the whole chain before it: no fallback possible) takes its
+//    logical index from an atomic ticket when the workgroup starts, so every lower index belongs to a workgroup that
+//    is running or done, and bounds the wait in time (s_memrealtime ticks, 100 MHz): on expiry it sets
+//    KPEG_ERR_TIMEOUT in the status word and goes on with what it has, so that kpeg_hip_sync() returns
+//    KPEG_HIP_E_DEVICE instead of the queue hanging.
+constexpr unsigned long long K0_SPIN_TICKS = 2000ull;         // 20 us, then the fallback
+constexpr unsigned long long K1_SPIN_TICKS = 2000000000ull;   // 20 s: a predecessor's wait includes the whole chain before it
+struct SpinGuard {
+    unsigned long long t0 = 0, limit;
+    uint32_t polls = 0;
+    __device__ __forceinline__ explicit SpinGuard(unsigned long long ticks) : limit(ticks) {}
+    // called after a failed poll; true = give up
+    __device__ __forceinline__ bool expired()
+    {
+        if (polls++ == 0) {
+            t0 = __builtin_amdgcn_s_memrealtime();
+            return false;
+        }
+        if (polls & 15) return false;   // a clock read every 16 polls
+        return __builtin_amdgcn_s_memrealtime() - t0 > limit;
+    }
 };
 
 struct EntropyScratch {
@@ -235,6 +263,8 @@ struct EntropyLaunch {
     int sync_passes;   // 0 = default
     int warm;          // warm-up sub-sequences per workgroup, < 0 = default (test hook: 0 makes every workgroup guess wrong)
     int subseq = 0;    // sub-sequence size: 0 = chosen from the bit rate, else SUBSEQ_SPARSE or SUBSEQ_DENSE (test hook)
+    unsigned long long spin_ticks = 0;   // bound of the waits between workgroups in 100 MHz ticks, 0 = defaults (test hook)
+    uint32_t fault = 0;                  // fault injection (test hook): bit 0 K0's, bit 1 K1's workgroup 0 never publishes
     // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
     // from the known state, DC predictors reset): d_scan / scan_len are unused, restart_interval = MCUs per image
     uint32_t nimg = 0;
@@ -306,6 +336,7 @@ __device__ void seg_setup_wg(EntropyMeta* meta, uint32_t* seg_off, uint32_t* sub
         for (int i = 0; i < SYNC_PASSES + 8; ++i) meta->moved[i] = 0;
         meta->total_blocks = 0;
         meta->ticket = 0;
+        meta->k1_order = 0;
     }
     if (nseg != expected_segs || nseg + 1 > seg_cap) {
         if (t == 0) {
@@ -363,17 +394,11 @@ struct UnstuffBatch {   // nimg > 0: workgroup g belongs to the image whose [wg_
     const uint32_t* len_tab;
     const uint32_t* wg_tab;
 };
-__global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
-                                                        uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
-                                                        uint32_t nsub_cap, uint32_t* status, UnstuffBatch bt, uint32_t expected_segs,
-                                                        uint32_t subseq_bits)
+// the image a K0 workgroup belongs to (fused batch), its index inside that image, the image's bytes
+__device__ __forceinline__ void us_locate(const UnstuffBatch& bt, uint32_t g, const uint8_t*& b, uint32_t& n, uint32_t& gl, uint32_t& img)
 {
-    __shared__ uint32_t s_wave[US_THREADS / 64];
-    __shared__ uint32_t s_base[2];
-    __shared__ uint32_t s_dep, s_last;
-    __shared__ uint32_t s_out[US_BLOCK_BYTES / 4 + 2];
-    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    uint32_t gl = g, img = 0;   // workgroup index inside its image
+    gl = g;
+    img = 0;
     if (bt.nimg) {
         uint32_t lo = 0, hi = bt.nimg;
         while (hi - lo > 1) {
@@ -386,6 +411,49 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         b = bt.scan_tab[img];
         n = bt.len_tab[img];
     }
+}
+
+// Look-back fallback: (kept bytes, markers) of workgroup j's 4 KiB, computed by one wavefront from the input bytes --
+// what workgroup j publishes as its aggregate.  Called with the whole wavefront converged.
+__device__ __attribute__((noinline)) unsigned long long us_aggregate_wave(const UnstuffBatch& bt, uint32_t j, const uint8_t* b, uint32_t n, bool rst)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t gl, img;
+    us_locate(bt, j, b, n, gl, img);
+    uint32_t k = 0, m = 0;
+    for (uint32_t s = 0; s < US_THREADS / 64; ++s) {
+        const uint32_t j0 = (gl * US_THREADS + s * 64 + lane) * US_BYTES_PER_THREAD;
+        const uint32_t nvalid = j0 >= n ? 0u : min((uint32_t)US_BYTES_PER_THREAD, n - j0);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t q = 0; q < nvalid; ++q) w[q >> 2] |= (uint32_t)b[j0 + q] << ((q & 3) * 8);
+        const uint32_t prev = j0 > 0 && j0 - 1 < n ? b[j0 - 1] : 0x100u;
+        const uint32_t next = j0 + US_BYTES_PER_THREAD < n ? b[j0 + US_BYTES_PER_THREAD] : 0x100u;
+        uint32_t km, mm;
+        us_flags(w, prev, next, nvalid, j0 + US_BYTES_PER_THREAD >= n, rst, km, mm);
+        k += __popc(km);
+        m += __popc(mm);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        k += __shfl_xor(k, o);
+        m += __shfl_xor(m, o);
+    }
+    return (unsigned long long)k | ((unsigned long long)m << 28);
+}
+
+__global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32_t n, int rst, unsigned long long* part, uint8_t* u,
+                                                        uint32_t* seg_off, uint32_t seg_cap, EntropyMeta* meta, uint32_t* sub_base,
+                                                        uint32_t nsub_cap, uint32_t* status, UnstuffBatch bt, uint32_t expected_segs,
+                                                        uint32_t subseq_bits, unsigned long long spin_ticks, uint32_t fault)
+{
+    __shared__ uint32_t s_wave[US_THREADS / 64];
+    __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_dep, s_last;
+    __shared__ uint32_t s_out[US_BLOCK_BYTES / 4 + 2];
+    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint8_t* const b0 = b;
+    const uint32_t n0 = n;
+    uint32_t gl = g, img = 0;   // workgroup index inside its image
+    us_locate(bt, g, b, n, gl, img);
     const uint32_t j0 = (gl * US_THREADS + t) * US_BYTES_PER_THREAD;
     const uint32_t nvalid = j0 >= n ? 0u : min((uint32_t)US_BYTES_PER_THREAD, n - j0);
     uint32_t w[4] = {0, 0, 0, 0};
@@ -419,13 +487,27 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
     if (t < 64) {
         // wavefront 0 looks back 64 predecessors at a time: the nearest inclusive prefix ends the walk
         const unsigned long long mine = (unsigned long long)tk | ((unsigned long long)tm << 28);
+        const bool mute = (fault & 1u) && g == 0 && gridDim.x > 1;   // test hook: workgroup 0 never publishes, its successors fall back
         if (lane == 0 && g > 0) __hip_atomic_store(&part[g], mine | LB_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t acc_k = 0, acc_m = 0;
         for (int base = (int)g - 1; base >= 0; base -= 64) {
             const int j = base - (int)lane;
             unsigned long long pv = LB_PFX;   // before the first workgroup: prefix 0
-            if (j >= 0)
-                while (((pv = __hip_atomic_load(&part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) __builtin_amdgcn_s_sleep(1);
+            if (j >= 0) {
+                SpinGuard guard(spin_ticks);
+                while (((pv = __hip_atomic_load(&part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) {
+                    if (guard.expired()) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            // predecessors that have published nothing within the bound (not dispatched yet, or whatever else):
+            // their aggregate from their input bytes, by this wavefront
+            for (unsigned long long pending = __ballot((pv >> 62) == 0); pending; pending &= pending - 1) {
+                const int L = __builtin_ctzll(pending);
+                const uint32_t jL = (uint32_t)__builtin_amdgcn_readlane(j, L);
+                const unsigned long long agg = us_aggregate_wave(bt, jL, b0, n0, rst != 0);
+                if ((int)lane == L) pv = agg | LB_AGG;
+            }
             const unsigned long long pfx = __ballot((pv >> 62) == 2);
             const uint32_t first = pfx ? (uint32_t)__builtin_ctzll(pfx) : 63u;
             uint32_t k = lane <= first ? (uint32_t)(pv & 0xFFFFFFFu) : 0u;
@@ -441,7 +523,7 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         if (lane == 0) {
             const unsigned long long acc = (unsigned long long)acc_k | ((unsigned long long)acc_m << 28);
             // (an exchange: its return means it has been performed, which the ticket at the end relies on)
-            s_dep = (uint32_t)atomicExch(&part[g], (acc + mine) | LB_PFX);
+            s_dep = mute ? 0u : (uint32_t)atomicExch(&part[g], (acc + mine) | LB_PFX);
             s_base[0] = acc_k;
             s_base[1] = acc_m;
         }
@@ -505,6 +587,7 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
                 for (int i = 0; i < SYNC_PASSES + 8; ++i) meta->moved[i] = 0;
                 meta->total_blocks = 0;
                 meta->ticket = 0;
+                meta->k1_order = 0;
             }
         }
         return;
@@ -798,7 +881,9 @@ struct SyncArgs {
     uint32_t nparts;
     uint32_t nwg_cap;
     int pass;
-    uint32_t* status;   // KPEG_SYNC_STATS builds only: words 8..13 collect loop counts
+    uint32_t* status;   // [1]: error flags (a chained wait that timed out); KPEG_SYNC_STATS builds: words 8..13 collect loop counts
+    unsigned long long spin_ticks;   // bound of the chained pass's wait for the predecessor (SpinGuard)
+    uint32_t fault;     // test hook: bit 1 = workgroup 0 of a rippling chained pass never publishes
 };
 constexpr uint64_t X_NONE = ~0ull;
 
@@ -883,9 +968,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     constexpr uint32_t STAGE_CAP = ITEMS * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
     const int p = a.pass;
-    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    uint32_t g = blockIdx.x;
+    const uint32_t t = threadIdx.x;
     const uint32_t nsub = a.meta->nsub;
-    const uint32_t i0 = g * OWN;
     // The last launch (chained) also scans the workgroup totals: at once by workgroup 0 if the pass
     // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
     const bool rippling = p >= 2 && a.meta->moved[p - 1] != 0;
@@ -893,6 +978,14 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         if (g == 0) wsum_scan<S>(a.wsum, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
         return;
     }
+    if (a.chained) {
+        // a rippling chained pass waits for its predecessor: logical index by ticket (see SpinGuard)
+        if (t == 0) s_n[0] = atomicAdd(&a.meta->k1_order, 1u);
+        __syncthreads();
+        g = s_n[0];
+        __syncthreads();
+    }
+    const uint32_t i0 = g * OWN;
     if (i0 >= nsub) return;
     if (p >= 2 && !rippling) return;  // converged
     auto finish_chained = [&]() {
@@ -908,14 +1001,22 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
     // Chained pass (the last one enqueued, only if the pass before it still moved something): every
     // workgroup waits until its predecessor has published its final exit state, so one launch ends the
-    // ripple however far it has to run (workgroups are dispatched in index order: the predecessor is
+    // ripple however far it has to run (g is the order in which the workgroups started: the predecessor is
     // running or done).  Streams that re-synchronise slowly (dense noise) end here; it costs a chain
     // of workgroup decodes, but no stream is given up.
+    const bool mute = a.chained && (a.fault & 2u) && g == 0;   // test hook: the successors time out
     uint64_t entry = 0;
     if (p >= 1) {
         if (a.chained && g > 0) {
             if (t == 0) {
-                while (__hip_atomic_load(&a.done[g - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                SpinGuard guard(a.spin_ticks);
+                while (__hip_atomic_load(&a.done[g - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    if (guard.expired()) {
+                        atomicOr(&a.status[1], KPEG_ERR_TIMEOUT);   // go on from whatever the predecessor has published so far
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
             }
             __syncthreads();
             entry = __hip_atomic_load(&Xb_cur[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -927,7 +1028,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             // the state this workgroup decoded from stands, and so do its results
             if (t == 0) {
                 Xb_cur[g] = Xb_prev[g];
-                if (a.chained) {
+                if (a.chained && !mute) {
                     __threadfence();
                     __hip_atomic_store(&a.done[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1095,7 +1196,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         const bool known = (s_geo[wu] >> 31) != 0;   // first own sub-sequence opens a restart segment
         a.assumed[g] = known ? X_NONE : s_X[wu];
         Xb_cur[g] = last;
-        if (a.chained) {
+        if (a.chained && !mute) {
             __threadfence();
             __hip_atomic_store(&a.done[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1268,6 +1369,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         constexpr uint32_t F_HEAD = 1u << 9, F_HEAD_NONCORNER = 1u << 10;   // the block open at entry ended here; its F_NONCORNER
         uint32_t F = s.q ? F_KEEP : 0u;
         uint32_t ebits = 0;                  // E_BAD / E_DCRUN of every entry met
+        uint32_t dcrange = 0;
         float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
         int nnz = 0;
         const uint32_t gbase = seg_mcu0 * 3;
@@ -1298,6 +1400,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             // a DC symbol opens block gbase + b; its value is coefficient 0
             const int n = pd0 + ext;
             if (isdc) {
+                dcrange |= (uint32_t)(n + 32768);   // bits above 15: the absolute DC does not fit the int16 coefficient layout
                 pd0 = pd1;
                 pd1 = pd2;
                 pd2 = n;
@@ -1350,6 +1453,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         if (ebits & E_BAD) err |= 8;
         if (ebits & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
         if (F & F_OVER) err |= 32;       // run past the end of a block
+        // the reference keeps its DC predictors as ints (MCU.cpp:107-112); one that leaves int16 would wrap here
+        // silently: outside the contract, reported instead
+        if (dcrange >> 16) err |= KPEG_ERR_DC_RANGE;
         head = (F & F_HEAD) != 0;
         hcorner = !(F & F_HEAD_NONCORNER);
         tail_gb = gb;
@@ -1505,7 +1611,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     if (!S->part_clean) ENT_HIP(hipMemsetAsync(S->d_part, 0, S->part_cap, L.stream));
     S->part_clean = false;
     hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, markers, (unsigned long long*)S->d_part,
-                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt, nseg_expected, (uint32_t)SUBSEQ_BITS);
+                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt, nseg_expected, (uint32_t)SUBSEQ_BITS,
+                       L.spin_ticks ? L.spin_ticks : K0_SPIN_TICKS, L.fault);
     mark(1);
 
     SyncArgs sa;
@@ -1528,6 +1635,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.warm = L.warm < 0 ? (uint32_t)WARM : min((uint32_t)L.warm, (uint32_t)WARM);
     sa.nwg_cap = nwg_cap;
     sa.status = L.d_status;
+    sa.spin_ticks = L.spin_ticks ? L.spin_ticks : K1_SPIN_TICKS;
+    sa.fault = L.fault;
     const int npass = L.sync_passes >= 3 ? L.sync_passes : SYNC_PASSES;   // the last one is chained and runs the scan
     sa.part = (unsigned long long*)S->d_part;
     sa.nparts = nparts;

@@ -11,6 +11,15 @@
 #include "Logger.hpp"
 #include "Utility.hpp"
 
+#ifndef KPEG_SRC_HASH
+#define KPEG_SRC_HASH "unstamped"
+#endif
+extern "C" const char* kpeg_host_build_hash( void )
+{
+    static const char stamp[] = "KPEG_SRC_HASH=" KPEG_SRC_HASH;
+    return stamp + 14;
+}
+
 extern "C" int kpeg_host_parse( const uint8_t* file, size_t size, unsigned flags, kpeg_frame* frame, uint8_t* scan, size_t scan_cap,
                                 size_t* scan_len )
 {

@@ -46,6 +46,12 @@ static int decodeJPEG( const std::string& filename, bool allowDRI )
     return EXIT_SUCCESS;
 }
 
+#ifndef KPEG_SRC_HASH
+#define KPEG_SRC_HASH "unstamped"
+#endif
+// libkpeg_amd/build.py looks for this string in the binary and rebuilds when the sources have changed
+extern "C" const char kpeg_cli_build_stamp[] = "KPEG_SRC_HASH=" KPEG_SRC_HASH;
+
 int main( int argc, char** argv )
 {
     try

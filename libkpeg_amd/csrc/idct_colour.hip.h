@@ -88,9 +88,12 @@ struct IdctParams {
 constexpr uint32_t KPEG_STATUS_WORDS = 16 + 256 + 64;   // [1] error flags, [2] K1 passes, [3] + [272..335] end-of-call tickets, [16..271] counters
 
 // End of a call's last kernel, every wavefront: the last one to get here hands the status words to the host
-// mirror (plain posted stores: no read over PCIe) and leaves the device words zero for the next call -- no
-// memset and no copy operation around a decode.  keep: the words stay (a batch lane accumulates error flags
-// and counters over its images; the mirror then always holds the sums so far).
+// mirror (plain posted stores: no read over PCIe) and leaves the device COUNTERS zero for the next call -- no
+// memset and no copy operation around a decode.  The error word [1] is sticky: it is never cleared here, so when
+// several calls are enqueued before one kpeg_hip_sync() an earlier call's error flags are still standing on the
+// device when a later call's epilogue copies them (kernels only OR into the word); kpeg_hip_sync() has the next
+// call clear it.  keep: every word stays (a batch lane accumulates error flags and counters over its images;
+// the mirror then always holds the sums so far).
 // No fences (a release fence writes back the XCD's whole L2: 1280 of them tripled K4's time): every status update
 // is a device-scope atomic performed at L2; `dep` is the value returned by this wavefront's own last update, so
 // that update has been performed before the ticket is taken, and the last wavefront reads the words at L2.
@@ -111,7 +114,7 @@ __device__ __forceinline__ void status_epilogue(uint32_t* status, uint32_t* h_st
         const bool ticket = w == 3 || w >= 272;
         const uint32_t v = ticket ? 0u : __hip_atomic_load(&status[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         h_status[w] = v;
-        if (!keep || ticket) status[w] = 0;
+        if (ticket || (!keep && w != 1)) status[w] = 0;
     }
 }
 

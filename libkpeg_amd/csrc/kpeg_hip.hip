@@ -33,6 +33,8 @@ struct kpeg_hip_ctx {
     int warm = -1;        // test hook: K1's warm-up sub-sequences per workgroup (< 0 = default)
     int subseq = 0;       // test hook: K1/K2 sub-sequence size (0 = from the bit rate)
     int batch_chunk = 4096;  // images per fused-batch chunk (test hook: small values exercise the chunk loop)
+    unsigned long long spin_ticks = 0;  // test hook: bound of the device-side waits between workgroups (100 MHz ticks, 0 = defaults)
+    uint32_t fault = 0;      // test hook: fault injection mask (entropy.hip.h: EntropyLaunch::fault)
     bool profiling = false;
     int num_cus = 256;
     int k4_waves_per_cu = K4_WAVES_PER_CU;  // K4's grid = num_cus * this (create: what the device keeps resident)
@@ -49,12 +51,13 @@ struct kpeg_hip_ctx {
     EntropyScratch ent;        // K0..K3 work buffers
     // [0] unused, [1] entropy error flag, [2] sync passes, [16..271] K4 exact-pixel counters
     uint32_t* d_status = nullptr;
-    uint32_t* h_status = nullptr;  // pinned mirror: the last kernel of every call adds the device words to it, kpeg_hip_sync reads and clears it
+    uint32_t* h_status = nullptr;  // pinned mirror: the last kernel of every call copies the device words to it (the error word [1] is sticky on the device until a sync has seen it), kpeg_hip_sync reads and clears it
     uint32_t* h_status_dev = nullptr;  // its device address
     bool status_clean = false;     // the device words are zero (the previous call's last kernel cleared them)
 
     enum { EV_BEGIN, EV_UNSTUFF, EV_SYNC, EV_SCAN, EV_WRITE, EV_DC, EV_IDCT, EV_COUNT };
     hipEvent_t ev[EV_COUNT] = {};
+    hipEvent_t switch_ev = nullptr;   // kpeg_hip_set_stream: the new stream waits for what is queued on the old one
     bool ev_rec[EV_COUNT] = {};
     kpeg_hip_timings timings = {};
     bool status_pending = false;
@@ -74,7 +77,10 @@ struct kpeg_hip_ctx {
     void* h_scan = nullptr;                // lane: pinned staging for host-buffer batches
     void* d_batch = nullptr;               // fused batch: descriptor blob (pointer tables, lengths)
     size_t batch_cap = 0;
-    void* h_batch = nullptr;               // ... its pinned staging
+    void* h_batch[2] = {nullptr, nullptr}; // ... its pinned staging, double-buffered: a call only waits for the upload of the call before last
+    hipEvent_t h_batch_ev[2] = {nullptr, nullptr};
+    bool h_batch_busy[2] = {false, false};
+    int h_batch_next = 0;
     size_t h_batch_cap = 0;
     size_t h_scan_cap = 0;
 };
@@ -108,6 +114,16 @@ static int grow(kpeg_hip_ctx* ctx, void** p, size_t* cap, size_t need)
 }
 
 extern "C" int kpeg_hip_abi_version(void) { return KPEG_HIP_ABI_VERSION; }
+
+#ifndef KPEG_SRC_HASH
+#define KPEG_SRC_HASH "unstamped"
+#endif
+// libkpeg_amd/build.py compares this with the hash of the sources in the tree and rebuilds on a mismatch
+extern "C" const char* kpeg_hip_build_hash(void)
+{
+    static const char stamp[] = "KPEG_SRC_HASH=" KPEG_SRC_HASH;
+    return stamp + 14;
+}
 
 extern "C" const char* kpeg_hip_strerror(int code)
 {
@@ -166,6 +182,7 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < kpeg_hip_ctx::EV_COUNT; ++i)
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->switch_ev, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&ctx->d_status, STATUS_BYTES)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&ctx->h_status, STATUS_BYTES, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
     std::memset(ctx->h_status, 0, STATUS_BYTES);
@@ -186,7 +203,10 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
         if (ctx->lane_ev[l]) (void)hipEventDestroy(ctx->lane_ev[l]);
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
-    if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->h_batch[i]) (void)hipHostFree(ctx->h_batch[i]);
+        if (ctx->h_batch_ev[i]) (void)hipEventDestroy(ctx->h_batch_ev[i]);
+    }
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     if (ctx->d_coef) (void)hipFree(ctx->d_coef);
     if (ctx->d_scan) (void)hipFree(ctx->d_scan);
@@ -197,6 +217,7 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < kpeg_hip_ctx::EV_COUNT; ++i)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -204,7 +225,14 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
 extern "C" int kpeg_hip_set_stream(kpeg_hip_ctx* ctx, void* s)
 {
     if (!ctx) return KPEG_HIP_E_ARG;
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    hipStream_t next = s ? (hipStream_t)s : ctx->own_stream;
+    if (next == ctx->stream) return KPEG_HIP_OK;
+    // The scratch buffers, the status words and the tables are ordered by the one stream only: work still queued
+    // on the old stream must have finished before anything launched on the new one touches them.
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventRecord(ctx->switch_ev, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(next, ctx->switch_ev, 0));
+    ctx->stream = next;
     return KPEG_HIP_OK;
 }
 
@@ -265,8 +293,15 @@ extern "C" int kpeg_hip_sync(kpeg_hip_ctx* ctx)
         ctx->timings.exact_pixels = ex;
         ctx->timings.sync_rounds = ctx->h_status[2];
         if (ctx->h_status[1] != 0) {
-            ctx->last_error = "entropy decode flagged the stream as invalid (code " + std::to_string(ctx->h_status[1]) + ")";
-            rc = KPEG_HIP_E_STREAM;
+            // error flags of every call enqueued since the last sync (the device word is sticky: status_epilogue)
+            if (ctx->h_status[1] & KPEG_ERR_TIMEOUT) {
+                ctx->last_error = "a device-side wait between workgroups timed out (code " + std::to_string(ctx->h_status[1]) + ")";
+                rc = KPEG_HIP_E_DEVICE;
+            } else {
+                ctx->last_error = "entropy decode flagged the stream as invalid (code " + std::to_string(ctx->h_status[1]) + ")";
+                rc = KPEG_HIP_E_STREAM;
+            }
+            ctx->status_clean = false;   // the next call clears the device words before it starts
         }
         std::memcpy(ctx->status_seen, ctx->h_status, STATUS_BYTES);
         std::memset(ctx->h_status, 0, STATUS_BYTES);   // the stream is idle: nothing is adding to it
@@ -449,6 +484,8 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.sync_passes = ctx->sync_passes;
     L.warm = ctx->warm;
     L.subseq = ctx->subseq;
+    L.spin_ticks = ctx->spin_ticks;
+    L.fault = ctx->fault;
     if (batch) {
         L.nimg = batch->nimg;
         L.d_scan_tab = batch->d_scan_tab;
@@ -613,15 +650,22 @@ static int decode_batch_fused(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f,
         if ((rc = grow(ctx, &ctx->d_batch, &ctx->batch_cap, blob))) return rc;
         if (blob > ctx->h_batch_cap) {
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
-            ctx->h_batch = nullptr;
+            for (int i = 0; i < 2; ++i) {
+                if (ctx->h_batch[i]) (void)hipHostFree(ctx->h_batch[i]);
+                ctx->h_batch[i] = nullptr;
+                ctx->h_batch_busy[i] = false;
+            }
             ctx->h_batch_cap = 0;
-            HIPCHK(ctx, hipHostMalloc(&ctx->h_batch, blob * 2, hipHostMallocDefault));
+            for (int i = 0; i < 2; ++i) HIPCHK(ctx, hipHostMalloc(&ctx->h_batch[i], blob * 2, hipHostMallocDefault));
             ctx->h_batch_cap = blob * 2;
-        } else {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the previous chunk's upload has left the staging buffer
         }
-        uint8_t* hb = (uint8_t*)ctx->h_batch;
+        const int hbi = ctx->h_batch_next;
+        ctx->h_batch_next ^= 1;
+        if (!ctx->h_batch_ev[hbi]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->h_batch_ev[hbi], hipEventDisableTiming));
+        // the upload that last used this staging buffer (two chunks ago) has left it: a wait for that copy only,
+        // not for the decodes queued since
+        if (ctx->h_batch_busy[hbi]) HIPCHK(ctx, hipEventSynchronize(ctx->h_batch_ev[hbi]));
+        uint8_t* hb = (uint8_t*)ctx->h_batch[hbi];
         const uint8_t** h_scan = (const uint8_t**)hb;
         uint8_t** h_rgb = (uint8_t**)(hb + (size_t)n * 8);
         uint32_t* h_len = (uint32_t*)(hb + (size_t)n * 16);
@@ -635,7 +679,9 @@ static int decode_batch_fused(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f,
             parts += (h_len[i] + US_BLOCK_BYTES - 1) / US_BLOCK_BYTES;
         }
         h_wg[n] = parts;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_batch, ctx->h_batch, blob, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_batch, hb, blob, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->h_batch_ev[hbi], ctx->stream));
+        ctx->h_batch_busy[hbi] = true;
         const uint8_t* db = (const uint8_t*)ctx->d_batch;
         EntropyLaunch B;
         B.nimg = (uint32_t)n;
@@ -768,7 +814,8 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
 
 // test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default),
 // key 3 = images per fused-batch chunk (0 = default), key 4 = sub-sequence size (0 = from the bit rate, else the sparse or the
-// dense size is forced)
+// dense size is forced), key 5 = bound of the device-side waits between workgroups in microseconds (0 = defaults), key 6 = fault
+// injection: bit 0 K0's, bit 1 the chained K1 pass's first workgroup never publishes (its successors must time out)
 extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
 {
     if (!ctx) return KPEG_HIP_E_ARG;
@@ -776,6 +823,8 @@ extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
     else if (key == 2) ctx->warm = value;
     else if (key == 3) ctx->batch_chunk = value > 0 && value <= 4096 ? value : 4096;
     else if (key == 4) ctx->subseq = value;
+    else if (key == 5) ctx->spin_ticks = value > 0 ? (unsigned long long)value * 100ull : 0ull;   // microseconds
+    else if (key == 6) ctx->fault = (uint32_t)value;
     else return KPEG_HIP_E_ARG;
     return KPEG_HIP_OK;
 }

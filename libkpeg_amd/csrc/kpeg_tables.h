@@ -2,6 +2,13 @@
 #pragma once
 #include <stdint.h>
 
+// Error flags (device status word [1]): 1 restart markers do not match the restart interval, 2 more sub-sequences than
+// planned for, 8 no such Huffman code, 16 DC symbol with a run nibble, 32 run past the end of a block, 64 / 128 a segment's
+// last block is incomplete / missing, 256 a wait on another workgroup timed out (kpeg_hip_sync: KPEG_HIP_E_DEVICE),
+// 512 an accumulated DC value outside int16 (the reference keeps ints, MCU.cpp:107-112: outside the contract).
+#define KPEG_ERR_TIMEOUT 256u
+#define KPEG_ERR_DC_RANGE 512u
+
 // cos((2a+1)*b*M_PI/16.0) as evaluated by glibc's libm on x86-64 (the values the
 // reference's MCU::computeIDCT sees, src/MCU.cpp:192-193), row a, column b, written
 // as hex doubles so that no libm is involved on the GPU box.  tests/test_tables.py

@@ -196,11 +196,15 @@ def oracle_decode_rst(data, restart_interval, nthreads=8):
     return oracle_idct_colour(coef, p.qt, p.width, p.height, nthreads), p, coef
 
 
-def ppm_bytes(rgb):
+def ppm_header(w, h):
     L = oracle()
     buf = ctypes.create_string_buffer(256)
-    n = L.kpeg_oracle_ppm_header(rgb.shape[1], rgb.shape[0], buf, 256)
-    return buf.raw[:n] + rgb.tobytes()
+    n = L.kpeg_oracle_ppm_header(w, h, buf, 256)
+    return buf.raw[:n]
+
+
+def ppm_bytes(rgb):
+    return ppm_header(rgb.shape[1], rgb.shape[0]) + rgb.tobytes()
 
 
 def sha256(b):

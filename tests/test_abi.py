@@ -24,7 +24,7 @@ def test_hip_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(libkpeg_amd.EXPORTS) == [n for n in names if n in libkpeg_amd.EXPORTS]
     assert set(libkpeg_amd.EXPORTS) == set(names), set(names) ^ set(libkpeg_amd.EXPORTS)
-    assert lib.kpeg_hip_abi_version() == 1
+    assert lib.kpeg_hip_abi_version() == libkpeg_amd.ABI_VERSION
     assert lib.kpeg_hip_strerror(-4) == b"corrupt or truncated entropy-coded data"
 
 
@@ -68,3 +68,21 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 txt = open(os.path.join(root, f), errors="ignore").read()
                 assert "kpeg_oracle" not in txt and "oracle/" not in txt.replace("oracle/)", ""), os.path.join(root, f)
+
+
+def test_binaries_carry_the_hash_of_the_sources_in_the_tree():
+    """A stale git-ignored .so must never reach the GPU box: every shipped binary is stamped with the hash of
+    the sources and flags it was built from, and build() rebuilds on a mismatch (libkpeg_amd/build.py)."""
+    import libkpeg_amd
+    from libkpeg_amd import build as B
+    hip = B.source_hash(B.hip_sources(), B.HIP_FLAGS + B.STRESS_DEFS)
+    host = B.source_hash(B.host_sources(), B.HOST_FLAGS)
+    pkg = os.path.join(ROOT, "libkpeg_amd")
+    assert B.stamped_hash(os.path.join(pkg, "libkpeg_hip.so")) == hip
+    assert B.stamped_hash(os.path.join(pkg, "libkpeg_hip_stress.so")) == hip
+    assert B.stamped_hash(os.path.join(pkg, "libkpeg.so")) == host
+    assert B.stamped_hash(os.path.join(pkg, "kpeg")) == host
+    assert libkpeg_amd.load_hip().kpeg_hip_build_hash().decode() == hip
+    H = libkpeg_amd.load_host()
+    H.kpeg_host_build_hash.restype = ctypes.c_char_p
+    assert H.kpeg_host_build_hash().decode() == host

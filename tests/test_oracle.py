@@ -116,3 +116,32 @@ def test_colour_known_answer():
 def test_ppm_header():
     hdr = T.ppm_bytes(np.zeros((8, 16, 3), np.uint8))[:-8 * 16 * 3]
     assert hdr == b"P6\n# PPM dump created using libKPEG: https://github.com/TheIllusionistMirage/libKPEG\n16 8\n255\n"
+
+
+# ---- BASELINE-sized and natural-content pins (tests/golden/make_golden_large.py: hashes from the real reference) ----
+LARGE = json.load(open(os.path.join(T.GOLDEN, "manifest_large.json")))
+
+
+@pytest.mark.parametrize("name", sorted(LARGE["natural"]))
+def test_oracle_matches_reference_on_photographs(name):
+    """Pillow encodings of photographs, 1-5 bits per pixel: other quantisers, optimised Huffman tables,
+    natural coefficient statistics (multi-round re-synchronisation on the GPU side)."""
+    g = LARGE["natural"][name]
+    data = _read(name)
+    assert T.sha256(data) == g["jpg_sha256"]
+    st, rgb = T.oracle_decode(data, nthreads=4)
+    assert st == T.DECODE_DONE and rgb.shape == (g["height"], g["width"], 3)
+    assert T.sha256(T.ppm_bytes(rgb)) == g["ppm_sha256"]
+
+
+def test_oracle_matches_reference_at_1080p():
+    """BASELINE config 2's input: the generator reproduces the pinned file byte for byte and the oracle the
+    reference's PPM (the 8K and 16384x16384 pins are checked on the GPU side, tests/test_gpu_large.py; the
+    generator script itself asserted oracle == reference on both)."""
+    g = LARGE["synth"]["1920x1080_seed1234"]
+    data = T.synth_jpeg(g["width"], g["height"], seed=g["seed"])
+    assert T.sha256(data) == g["jpg_sha256"]
+    st, rgb = T.oracle_decode(data, nthreads=8)
+    assert st == T.DECODE_DONE
+    assert T.sha256(T.ppm_bytes(rgb)) == g["ppm_sha256"]
+    assert T.sha256(rgb.tobytes()) == g["rgb_sha256"]
