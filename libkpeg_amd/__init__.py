@@ -76,7 +76,17 @@ def load_hip():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = ctypes.CDLL(HIP_LIB)
+    _lib = _declare(ctypes.CDLL(HIP_LIB))
+    return _lib
+
+
+def load_variant(path):
+    """Another build of the library beside the default one (kernel A/B experiments, tools/k4_ab.py)."""
+    load_hip()
+    return _declare(ctypes.CDLL(path))
+
+
+def _declare(L):
     vp, c_int, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     FP = ctypes.POINTER(Frame)
     L.kpeg_hip_abi_version.restype = c_int
@@ -101,15 +111,14 @@ def load_hip():
     L.kpeg_hip_decode_scan_dev.argtypes = [vp, FP, vp, sz, vp]
     L.kpeg_hip_decode_stripe_dev.argtypes = [vp, FP, vp, sz, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.kpeg_hip_entropy_decode_dev.argtypes = [vp, FP, vp, sz, vp]
-    _lib = L
     return L
 
 
 class Context:
     """Thin RAII wrapper over kpeg_hip_ctx."""
 
-    def __init__(self, device=0):
-        self.lib = load_hip()
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or load_hip()
         self._h = ctypes.c_void_p()
         rc = self.lib.kpeg_hip_create(ctypes.byref(self._h), device)
         if rc != OK:

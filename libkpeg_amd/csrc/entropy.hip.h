@@ -210,7 +210,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
 //    is running or done, and bounds the wait in time (s_memrealtime ticks, 100 MHz): on expiry it sets
 //    KPEG_ERR_TIMEOUT in the status word and goes on with what it has, so that kpeg_hip_sync() returns
 //    KPEG_HIP_E_DEVICE instead of the queue hanging.
-constexpr unsigned long long K0_SPIN_TICKS = 2000ull;         // 20 us, then the fallback
+constexpr unsigned long long K0_SPIN_TICKS = 50000ull;        // 0.5 ms (a predecessor's 4 KiB take microseconds), then the fallback
 constexpr unsigned long long K1_SPIN_TICKS = 2000000000ull;   // 20 s: a predecessor's wait includes the whole chain before it
 struct SpinGuard {
     unsigned long long t0 = 0, limit;
@@ -415,7 +415,7 @@ __device__ __forceinline__ void us_locate(const UnstuffBatch& bt, uint32_t g, co
 
 // Look-back fallback: (kept bytes, markers) of workgroup j's 4 KiB, computed by one wavefront from the input bytes --
 // what workgroup j publishes as its aggregate.  Called with the whole wavefront converged.
-__device__ __attribute__((noinline)) unsigned long long us_aggregate_wave(const UnstuffBatch& bt, uint32_t j, const uint8_t* b, uint32_t n, bool rst)
+__device__ __forceinline__ unsigned long long us_aggregate_wave(const UnstuffBatch& bt, uint32_t j, const uint8_t* b, uint32_t n, bool rst)
 {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t gl, img;
@@ -492,21 +492,24 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         uint32_t acc_k = 0, acc_m = 0;
         for (int base = (int)g - 1; base >= 0; base -= 64) {
             const int j = base - (int)lane;
-            unsigned long long pv = LB_PFX;   // before the first workgroup: prefix 0
-            if (j >= 0) {
-                SpinGuard guard(spin_ticks);
-                while (((pv = __hip_atomic_load(&part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) {
-                    if (guard.expired()) break;
+            unsigned long long pv = j >= 0 ? 0ull : LB_PFX;   // before the first workgroup: prefix 0
+            // Poll the 64 predecessors together.  One that has published nothing within the bound (not dispatched yet, or
+            // whatever else) gets its aggregate computed here from its input bytes -- the nearest such predecessor only,
+            // then the poll goes on: a merely slow neighbourhood costs one fallback per bound, not sixty-four.
+            SpinGuard guard(spin_ticks);
+            for (;;) {
+                if (j >= 0 && (pv >> 62) == 0) pv = __hip_atomic_load(&part[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long pending = __ballot((pv >> 62) == 0);
+                if (!pending) break;
+                if (!guard.expired()) {   // (every lane polls in step: the guard's state is wave-uniform)
                     __builtin_amdgcn_s_sleep(1);
+                    continue;
                 }
-            }
-            // predecessors that have published nothing within the bound (not dispatched yet, or whatever else):
-            // their aggregate from their input bytes, by this wavefront
-            for (unsigned long long pending = __ballot((pv >> 62) == 0); pending; pending &= pending - 1) {
                 const int L = __builtin_ctzll(pending);
                 const uint32_t jL = (uint32_t)__builtin_amdgcn_readlane(j, L);
                 const unsigned long long agg = us_aggregate_wave(bt, jL, b0, n0, rst != 0);
                 if ((int)lane == L) pv = agg | LB_AGG;
+                guard = SpinGuard(spin_ticks);
             }
             const unsigned long long pfx = __ballot((pv >> 62) == 2);
             const uint32_t first = pfx ? (uint32_t)__builtin_ctzll(pfx) : 63u;

@@ -260,10 +260,12 @@ constexpr int TILE_MCUS = 8;                    // MCUs per wavefront iteration 
 constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 192
 constexpr int TILE_ROW_STRIDE = 208;            // padded: 13 x 16 bytes, conflict-free b64 writes across rows
 constexpr int QUEUE_CAP = 64;                   // queue entries per wavefront (fix-ups run from QUEUE_FLUSH entries on); pixels beyond go to the overflow list
-#ifndef KPEG_K4_OCC
-#define KPEG_K4_OCC 5
+#ifndef KPEG_K4_WAVES
+#define KPEG_K4_WAVES 16
 #endif
-constexpr int K4_WAVES_PER_CU = 4 * KPEG_K4_OCC;  // one wavefront per workgroup, KPEG_K4_OCC per SIMD
+// K4's workgroup: as many wavefronts as a CU is to hold (4 SIMDs x 4), ONE workgroup per CU.  The wavefronts are independent
+// workers (no barrier after the start-up); what they share is the LDS counter that hands out the workgroup's tiles.
+constexpr int K4_WAVES = KPEG_K4_WAVES, K4_THREADS = 64 * K4_WAVES;
 
 // 1-D 8-point inverse DCT kernel sum_v a[v] cos((2y+1) v pi/16), y = 0..7, in place.
 // NV < 8: a[NV..7] are known to be zero and their terms are left out.  fma(0, c, x) == x and
@@ -277,13 +279,20 @@ __device__ __forceinline__ void row_idct8(float a[8])
                 c7 = 0.19509032201612826785f;
     float t0 = NV > 4 ? __builtin_fmaf(a[4], c4, a[0]) : a[0];
     float t1 = NV > 4 ? __builtin_fmaf(a[4], -c4, a[0]) : a[0];
-    float p = NV > 6 ? __builtin_fmaf(a[6], c6, a[2] * c2) : a[2] * c2;
-    float q = NV > 6 ? __builtin_fmaf(a[6], -c2, a[2] * c6) : a[2] * c6;
-    float e0 = t0 + p, e3 = t0 - p, e1 = t1 + q, e2 = t1 - q;
-    float o0 = __builtin_fmaf(a[3], c3, a[1] * c1);
-    float o1 = __builtin_fmaf(a[3], -c7, a[1] * c3);
-    float o2 = __builtin_fmaf(a[3], -c1, a[1] * c5);
-    float o3 = __builtin_fmaf(a[3], -c5, a[1] * c7);
+    float e0, e1, e2, e3, o0, o1, o2, o3;
+    if (NV > 2) {
+        float p = NV > 6 ? __builtin_fmaf(a[6], c6, a[2] * c2) : a[2] * c2;
+        float q = NV > 6 ? __builtin_fmaf(a[6], -c2, a[2] * c6) : a[2] * c6;
+        e0 = t0 + p, e3 = t0 - p, e1 = t1 + q, e2 = t1 - q;
+        o0 = __builtin_fmaf(a[3], c3, a[1] * c1);
+        o1 = __builtin_fmaf(a[3], -c7, a[1] * c3);
+        o2 = __builtin_fmaf(a[3], -c1, a[1] * c5);
+        o3 = __builtin_fmaf(a[3], -c5, a[1] * c7);
+    } else {
+        // a[2..7] == 0: p = q = +0 and the fma's addend terms are +-0, which change no value (x + 0 == x)
+        e0 = e1 = e2 = e3 = t0;
+        o0 = a[1] * c1, o1 = a[1] * c3, o2 = a[1] * c5, o3 = a[1] * c7;
+    }
     if (NV > 5) {
         o0 = __builtin_fmaf(a[5], c5, o0);
         o1 = __builtin_fmaf(a[5], -c1, o1);
@@ -362,6 +371,21 @@ __device__ __forceinline__ void column_idct8(const float g[8], float k0, float k
         : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
         : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(k0), "v"(k1),
           "v"(k2), "v"(k3), "v"(s));
+    } else if (NU <= 2) {
+    asm("s_nop 1\n\t"
+        KPEG_DPP8("v_mul_f32_dpp", "quad_perm:[0,0,0,0]", "%16")
+        "v_fmac_f32_dpp %0, %0, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %20 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(k0), "v"(k1),
+          "v"(k2), "v"(k3), "v"(s));
     } else {
     asm("s_nop 1\n\t"
         KPEG_DPP8("v_mul_f32_dpp", "quad_perm:[0,0,0,0]", "%16")
@@ -382,7 +406,7 @@ __device__ __forceinline__ void column_idct8(const float g[8], float k0, float k
 #undef KPEG_DPP8
 }
 
-__device__ __forceinline__ float cosf_tab(int k)  // cos(k*pi/16), k = 0..31, f32-rounded
+__host__ __device__ constexpr float cosf_tab(int k)  // cos(k*pi/16), k = 0..31, f32-rounded
 {
     const float t[9] = {1.0f,
                         0.98078528040323044913f,
@@ -424,8 +448,10 @@ __device__ __forceinline__ void block_fast(const uint4 d, const LaneConst& lc, c
     // AC input scale 0.25 * cc[u][v] * Q[u][v] of this lane's row, from LDS (m[0] unused)
     const float4 mlo = *reinterpret_cast<const float4*>(m);
     a[1] *= mlo.y;
-    a[2] *= mlo.z;
-    a[3] *= mlo.w;
+    if (N > 2) {
+        a[2] *= mlo.z;
+        a[3] *= mlo.w;
+    }
     if (N > 4) {
         const float4 mhi = *reinterpret_cast<const float4*>(m + 4);
         a[4] *= mhi.x;
@@ -537,6 +563,15 @@ __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, 
     return level_shift((float)(0.25 * (double)sum));
 }
 
+#ifndef KPEG_K4_MAX3
+#define KPEG_K4_MAX3 0
+#endif
+#ifndef KPEG_K4_CHROMA2
+#define KPEG_K4_CHROMA2 0
+#endif
+#ifndef KPEG_K4_LUMA4
+#define KPEG_K4_LUMA4 0
+#endif
 #ifndef KPEG_QUEUE_FLUSH
 #define KPEG_QUEUE_FLUSH 32
 #endif
@@ -544,10 +579,14 @@ constexpr int QUEUE_FLUSH = KPEG_QUEUE_FLUSH;   // queued pixels that make a fix
 constexpr int OVER_CAP = TILE_MCUS * 64 - (QUEUE_CAP - QUEUE_FLUSH);   // a tile starts with at least QUEUE_CAP - QUEUE_FLUSH free entries
 constexpr int QUEUE_WORDS = 8;    // per queued pixel: position, 3 rounded samples, 3 keys (>= 0: that component is unsafe), pad
 
-// One wavefront per workgroup: no workgroup barrier anywhere, every wave is an independent
-// worker walking its own tiles of 8 MCUs (64 x 8 pixels).  Small register footprint on purpose:
-// VALU issue on gfx950 needs >= 4 resident waves per SIMD to approach its rate
-// (tools/ubench/valu_rate.hip).
+#ifdef KPEG_K4_STAMP
+__device__ unsigned long long g_k4_stamp[8192 * 4];
+#endif
+// One workgroup of K4_WAVES wavefronts per CU; every wavefront is an independent worker on tiles of 8 MCUs (64 x 8
+// pixels), no barrier after the start-up.  The workgroup owns a contiguous range of tiles and hands them out through a
+// counter in LDS: on a SIMD the oldest wavefront gets the issue slots first (age arbitration), so with a static split the
+// wavefronts of one SIMD finished one after the other -- first 38 us, last 54-66 us, the SIMD two-thirds idle at the end
+// (profiles/r02: per-wavefront stamps) -- whereas wavefronts that take tiles as they go all finish together.
 //
 // Pixels whose fast value cannot be trusted (within the block's bound of a rounding boundary, or a G term too
 // close to an integer) are only *noted* in the tile loop: their position goes to a small queue in LDS.  Once the
@@ -555,46 +594,72 @@ constexpr int QUEUE_WORDS = 8;    // per queued pixel: position, 3 rounded sampl
 // per (pixel, component), and patches the three bytes in global memory.  Handling them where they are found -- a few
 // lanes of a wavefront, several times per tile -- cost 37 % of the kernel's time (profiles/r01_g: 0.103 -> 0.065 ms with
 // the handling compiled out).
-__global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams p, QTables qt)
+__global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, QTables qt)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[8 * TILE_ROW_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_queue[QUEUE_CAP * QUEUE_WORDS];
-    __shared__ uint16_t s_over[OVER_CAP];   // unsafe pixels a tile has beyond the queue's room: bits [11:0] of the position word (the
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile_all[K4_WAVES][8 * TILE_ROW_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_queue_all[K4_WAVES][QUEUE_CAP * QUEUE_WORDS];
+    __shared__ uint16_t s_over_all[K4_WAVES][OVER_CAP];   // unsafe pixels a tile has beyond the queue's room: bits [11:0] of the position word (the
                                             // fix-up pass that takes them runs before the next tile: the tile is known)
     __shared__ __attribute__((aligned(16))) float s_m[2][64];     // AC input scales, natural order
     __shared__ __attribute__((aligned(16))) uint32_t s_qi[2][64]; // quantisers (exact dequantisation in the fix-up pass)
     __shared__ double s_cos[64];
+    __shared__ uint32_t s_next;       // next tile of this workgroup's range to hand out
+    __shared__ uint32_t s_wg[2];      // [0] wavefronts of this workgroup that are done, [1] unsafe pixels they counted
 
-    const int tid = threadIdx.x;
+#ifdef KPEG_K4_STAMP
+    // diagnostic build only (tools/k4_clock.py): the shader clock this kernel runs at = d(s_memtime) / d(s_memrealtime) x 100 MHz
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x & 63;   // lane of the wavefront
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint8_t* const s_tile = s_tile_all[wave];
+    uint32_t* const s_queue = s_queue_all[wave];
+    uint16_t* const s_over = s_over_all[wave];
     const int lane8 = tid & 7;          // lane within the MCU group = output pixel row
     const int grp = tid >> 3;           // MCU within the tile, 0..7
     const int u = lane8 < 4 ? 2 * lane8 : 2 * (lane8 - 4) + 1;  // coefficient row this lane loads
 
-    for (int i = tid; i < 128; i += 64) {
-        const int t = i >> 6, k = i & 63;
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x >> 6, k = threadIdx.x & 63;
         s_m[t][k] = 0.25f * cc_of(k >> 3, k & 7) * (float)qt.q[t][k];
         s_qi[t][k] = qt.q[t][k];
+    } else if (threadIdx.x < 192) {
+        s_cos[tid] = c_cos[tid];
+    } else if (threadIdx.x == 192) {
+        s_next = 0;
+        s_wg[0] = 0;
+        s_wg[1] = 0;
     }
-    s_cos[tid] = c_cos[tid];
+    // this workgroup's tiles: [wg_tile0, wg_tile0 + wg_ntiles)
+    const uint32_t wg_tile0 = (uint32_t)(((unsigned long long)p.ntiles * blockIdx.x) / gridDim.x);
+    const uint32_t wg_ntiles = (uint32_t)(((unsigned long long)p.ntiles * (blockIdx.x + 1)) / gridDim.x) - wg_tile0;
     LaneConst lc;
     lc.q0[0] = (float)qt.q[0][u * 8];
     lc.q0[1] = (float)qt.q[1][u * 8];
     lc.cc0 = cc_of(u, 0);
-    if (lane8 < 4) {
-        // rows 0,2,4,6 live on lanes 0..3; this lane accumulates E_x, x = lane8
+    // Column-pass constants of this lane: rows 0,2,4,6 live on lanes 0..3, lane x accumulates E_x with cos((2x+1) 2k pi/16);
+    // rows 1,3,5,7 on lanes 4..7, lane 7-x accumulates -O_x with -cos((2x+1)(2k+1) pi/16).  Literals picked by a select
+    // chain: a table in memory indexed by the lane cost every wavefront sixteen serialised loads before its first tile.
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lc.k[k] = cosf_tab((2 * lane8 + 1) * (2 * k));
-    } else {
-        // rows 1,3,5,7 live on lanes 4..7; this lane accumulates -O_x, x = 7 - lane8
-        const int x = 7 - lane8;
+    for (int k = 0; k < 4; ++k) {
+        float r = cosf_tab(1 * (2 * k));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lc.k[k] = -cosf_tab((2 * x + 1) * (2 * k + 1));
+        for (int l = 1; l < 8; ++l) {
+            const float c = l < 4 ? cosf_tab((2 * l + 1) * (2 * k)) : -cosf_tab((2 * (7 - l) + 1) * (2 * k + 1));
+            r = lane8 == l ? c : r;
+        }
+        lc.k[k] = r;
     }
     // combine: out = own + mirror * s.  Even lane x: E_x - (-O_x) -> s = -1;
     // odd lane (pixel row 7-x): E_x - O_x = mirror(E_x) + own(-O_x) -> s = +1.
     lc.s = lane8 < 4 ? -1.0f : 1.0f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();   // the tables and the tile counter stand (the only workgroup barrier)
+    // takes the next tile of the workgroup's range: the value is asked for one tile ahead, so the LDS round trip is not waited for
+    auto take_tile = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (tid == 0) t = atomicAdd(&s_next, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
 
     // Coalesced write-back of a finished tile from LDS: 8 rows x nm*24 bytes as 16-byte chunks
     // (8 x 12 = 96 chunks: lanes 0..47 store chunk k of row r and of row r + 4; two registers per lane hold it all).
@@ -654,7 +719,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
 
     // Fix-up passes.  A queue entry is a pixel of one of this wavefront's tiles:
     //   word 0: [2:0] MCU within the tile, [5:3] pixel row, [8:6] pixel column, [11:9] component blocks that are
-    //           corner-only (the sign of their bound), [31:12] the tile's sequence number k (tile = blockIdx.x + k * gridDim.x);
+    //           corner-only (the sign of their bound), [31:12] the tile's number k inside the workgroup's range (tile = wg_tile0 + k);
     //   words 1..3: the three rounded fast samples (minus the level shift); words 4..6: their keys (>= 0: unsafe).
     // nq queued entries, then nover pixels of the overflow list: position words only (a tile with more unsafe pixels
     // than the queue had room for: clusters of ties, adversarial input), all components to be evaluated.  One lane per entry.  Unsafe components of corner-only blocks are settled by the lane itself
@@ -684,7 +749,7 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 }
             }
             const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
-            const uint32_t tile = blockIdx.x + (pos >> 12) * gridDim.x;
+            const uint32_t tile = wg_tile0 + (pos >> 12);
             const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
             const uint32_t m0 = tcol * TILE_MCUS;
             const uint32_t mcu = trow * p.mcus_w + m0 + g;
@@ -820,22 +885,52 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
     uint32_t nq = 0;           // queued positions (wave-uniform)
     uint32_t nover = 0;        // entries of the overflow list
     uint32_t nq_total = 0;
-    for (uint32_t tile = blockIdx.x, tilek = 0;; tile += gridDim.x, ++tilek) {
-        const bool more = tile < p.ntiles;
+    // A tile's inputs: one 16-byte coefficient row of each component block and the three blocks' bounds.  They are asked
+    // for one tile ahead (a second register set: the 16-wavefront workgroup leaves 128 VGPRs per lane), so that a
+    // wavefront's tile costs it its instructions and not a memory round trip on top -- with four wavefronts per SIMD the
+    // others cannot cover that wait.
+    struct TileIn {
+        uint4 d0, d1, d2;
+        float e0, e1, e2;
+    };
+    auto issue_loads = [&](uint32_t tk, TileIn& in) {
+        const uint32_t tile = wg_tile0 + tk;
+        const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
+        const uint32_t m0 = tcol * TILE_MCUS;
+        const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
+        // MCU of this lane's group (groups beyond the image re-read the tile's first MCU; their pixels are never stored).
+        // Addresses are a scalar base (the tile's first MCU) plus a 32-bit lane offset: global_load with an SGPR base.
+        uint32_t lane_mcu = (uint32_t)grp < nm ? (uint32_t)grp : 0u;
+        asm volatile("" : "+v"(lane_mcu));
+#ifdef KPEG_ABLATE_SAMETILE
+        // timing experiment: every tile reads the coefficients of one of 64 tiles (cache-resident): what the kernel costs without its HBM reads
+        const size_t mcu_ld = (size_t)(tile & 63u) * TILE_MCUS;
+#else
+        const size_t mcu_ld = (size_t)trow * p.mcus_w + m0;
+#endif
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu_ld * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
+        in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+        const float* eb = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(p.ebound + mcu_ld * 3) + lane_mcu * 12u);
+        in.e0 = eb[0], in.e1 = eb[1], in.e2 = eb[2];
+    };
+    uint32_t tilek_cur = take_tile(), tilek_next = take_tile();
+    TileIn cur, nxt;
+    if (tilek_cur < wg_ntiles) issue_loads(tilek_cur, cur);
+    for (;;) {
+        const uint32_t tilek = tilek_cur;              // this tile's number inside the workgroup's range
+        const bool more = tilek < wg_ntiles;           // wave-uniform
+        const uint32_t tile = wg_tile0 + tilek;
+        uint32_t tilek_after = 0;
         if (more) {
+        tilek_after = take_tile();
+        if (tilek_next < wg_ntiles) issue_loads(tilek_next, nxt);   // the next tile's inputs travel while this one is computed
+        asm volatile("" ::: "memory");
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
         const bool active = (uint32_t)grp < nm;
-        // MCU of this lane's group (groups beyond the image re-read the tile's first MCU; their pixels are never stored).
-        // Addresses are a scalar base (the tile's first MCU) plus a 32-bit lane offset: global_load with an SGPR base.
-        const size_t mcu0 = (size_t)trow * p.mcus_w + m0;
-        uint32_t lane_mcu = active ? (uint32_t)grp : 0u;
-        asm volatile("" : "+v"(lane_mcu));
-        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu0 * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
-        const uint4 d0 = src[0], d1 = src[8], d2 = src[16];
-        const float* eb = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(p.ebound + mcu0 * 3) + lane_mcu * 12u);
-        const float e0 = eb[0], e1 = eb[1], e2 = eb[2];
+        const uint4 d0 = cur.d0, d1 = cur.d1, d2 = cur.d2;
+        const float e0 = cur.e0, e1 = cur.e1, e2 = cur.e2;
         const size_t cur_off = tile_offset(trow, m0);
         if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
         have_prev = true;
@@ -853,15 +948,37 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
         // Quantised high frequencies are mostly zero: if no block of this wavefront has a coefficient outside
         // its top-left 6x6 (luma) / 4x4 (chroma) corner, the terms of the empty rows and columns are left out
         // (same floats as the full transform, see row_idct8).  8K q75: luma 6x6 for 98 % of the tiles, chroma 4x4 for 99 %.
+#if KPEG_K4_LUMA4
+        // (a third luma size: 4x4 -- what smooth content quantises to)
+        if (__ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0)) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        else if (__ballot((d0.z | (u >= 4 ? (d0.x | d0.y) : 0u)) != 0)) block_fast<6>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        else block_fast<4>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+#else
         if (__ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0)) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
         else block_fast<6>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+#endif
+#if KPEG_K4_CHROMA2
+        // chroma blocks of smooth content rarely have anything outside their 2x2 corner (DC and the two first-order terms)
+        if (__ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0)) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        else if (__ballot((d1.y | (u >= 2 ? d1.x : 0u)) != 0)) block_fast<4>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        else block_fast<2>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        else if (__ballot((d2.y | (u >= 2 ? d2.x : 0u)) != 0)) block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        else block_fast<2>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+#else
         if (__ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0)) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
         else block_fast<4>(d1, lc, &s_m[1][u * 8], 1, v[1]);
         if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
         else block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
 #endif
+#endif
         // |fast - rint(fast)| + nthr >= 0  <=>  within the block's bound of a rounding boundary
         const float nthr0 = fabsf(e0) - 0.5f, nthr1 = fabsf(e1) - 0.5f, nthr2 = fabsf(e2) - 0.5f;
+#if KPEG_K4_MAX3
+        // one test for the three samples of a pixel: the largest of the three distances against the largest of the three
+        // bounds (conservative; v_max3_f32 + one add instead of three adds and two ands per pixel)
+        const float nthr_max = fmaxf(fmaxf(fabsf(e0), fabsf(e1)), fabsf(e2)) - 0.5f;
+#endif
         // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
         const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
         const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
@@ -884,7 +1001,12 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                 const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
                 const float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
                 // >= 0: the fast value is within its block's bound of a rounding boundary
+#if KPEG_K4_MAX3
+                const float dy = vy - ry, db = vb - rb, dr = vr - rr;
+                const float fall = fmaxf(fmaxf(fabsf(dy), fabsf(db)), fabsf(dr)) + nthr_max;
+#else
                 const float fy = fabsf(vy - ry) + nthr0, fb = fabsf(vb - rb) + nthr1, fr = fabsf(vr - rr) + nthr2;
+#endif
                 // colour from the three rounded samples (minus the level shift); dt = how far the G term's t is from
                 // an integer, as seen by the f32 arithmetic
                 // v_cvt_pk_u8_f32 rounds to nearest-even and saturates.  All three channels are handed to it 0.499 below
@@ -916,7 +1038,11 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                         kg = 0x80000000u;   // G is exact here
                     }
                 }
+#if KPEG_K4_MAX3
+                const uint32_t safe = __float_as_uint(fall) & kg;
+#else
                 const uint32_t safe = __float_as_uint(fy) & __float_as_uint(fb) & __float_as_uint(fr) & kg;
+#endif
                 pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
                 pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
                 pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
@@ -932,7 +1058,12 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
                             q[0] = pw;
 #ifndef KPEG_PUSH_POS_ONLY
                             q[1] = __float_as_uint(ry), q[2] = __float_as_uint(rb), q[3] = __float_as_uint(rr);
+#if KPEG_K4_MAX3
+                            // per component, with its own bound (a pixel flagged by the common test may need nothing)
+                            q[4] = __float_as_uint(fabsf(dy) + nthr0), q[5] = __float_as_uint(fabsf(db) + nthr1), q[6] = __float_as_uint(fabsf(dr) + nthr2);
+#else
                             q[4] = __float_as_uint(fy), q[5] = __float_as_uint(fb), q[6] = __float_as_uint(fr);
+#endif
 #endif
                         } else {
                             s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
@@ -975,16 +1106,47 @@ __global__ __launch_bounds__(64, KPEG_K4_OCC) void k_idct_colour_fast(IdctParams
             nover = 0;
         }
         if (!more) break;
+        cur = nxt;
+        tilek_cur = tilek_next;
+        tilek_next = tilek_after;
     }
     if (have_prev) write_back(prev_off, prev_nm);
-    // one fire-and-forget add per wavefront, spread over 256 words (a single hot word serialises in L2)
-    uint32_t dep = 0;
 #if defined(KPEG_COUNT_COOP) || defined(KPEG_COUNT_MANY) || defined(KPEG_COUNT_FLUSH) || defined(KPEG_COUNT_CORNER)
     nq_total = dbg_count;
 #else
     (void)dbg_count;
 #endif
-    if (tid == 0 && nq_total && p.stats) dep = atomicAdd(&p.stats[blockIdx.x & 255], nq_total);
+#ifdef KPEG_K4_STAMP
+    if (tid == 0) {
+        const unsigned long long dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        const uint32_t w = blockIdx.x * K4_WAVES + wave;
+        if (w < 8192) {
+            // every wavefront's start, end (100 MHz ticks), lifetime in shader cycles, to a slot of its own (a buffer nothing else reads)
+            g_k4_stamp[w * 4 + 0] = stamp_r0;
+            g_k4_stamp[w * 4 + 1] = stamp_r0 + dr;
+            g_k4_stamp[w * 4 + 2] = dc;
+            // unsafe pixels [63:48] | XCC_ID [35:32] | HW_ID [31:0] (wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+            g_k4_stamp[w * 4 + 3] = ((unsigned long long)(nq_total & 0xFFFFu) << 48) |
+                                    ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 32) |
+                                    __builtin_amdgcn_s_getreg(4 | (31 << 11));
+        }
+    }
+#endif
+    // The workgroup's last wavefront adds the workgroup's count of unsafe pixels to the statistics (spread over 256 words:
+    // a single hot word serialises in L2) and takes the workgroup's end-of-call ticket.
+    uint32_t last_of_wg = 0;
+    if (tid == 0) {
+        if (nq_total) atomicAdd(&s_wg[1], nq_total);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        last_of_wg = atomicAdd(&s_wg[0], 1u) == (uint32_t)K4_WAVES - 1 ? 1u : 0u;
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)last_of_wg)) return;
+    uint32_t dep = 0;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t n = s_wg[1];
+        if (n && p.stats) dep = atomicAdd(&p.stats[blockIdx.x & 255], n);
+    }
     status_epilogue(p.status, p.h_status, gridDim.x, p.keep_status, dep);
 }
 

@@ -37,7 +37,7 @@ struct kpeg_hip_ctx {
     uint32_t fault = 0;      // test hook: fault injection mask (entropy.hip.h: EntropyLaunch::fault)
     bool profiling = false;
     int num_cus = 256;
-    int k4_waves_per_cu = K4_WAVES_PER_CU;  // K4's grid = num_cus * this (create: what the device keeps resident)
+    int k4_wgs_per_cu = 1;   // K4's grid = num_cus * this (create: what the device keeps resident)
 
     // device scratch (grown on demand, never shrunk)
     void* d_coef = nullptr;
@@ -167,15 +167,15 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
     }
     ctx->num_cus = prop.multiProcessorCount;
     {
-        // K4's wavefronts are persistent workers: launch exactly as many as stay resident (more would run as a
-        // second, partly filled round).  KPEG_K4_WAVES_PER_CU: timing experiments only.
+        // K4's workgroups are persistent workers, one per CU (K4_WAVES wavefronts each): launch exactly as many as stay
+        // resident (more would run as a second, partly filled round).  KPEG_K4_WGS_PER_CU: timing experiments only.
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_idct_colour_fast, 64, 0) == hipSuccess && nb > 0) ctx->k4_waves_per_cu = nb;
-        if (const char* s = std::getenv("KPEG_K4_WAVES_PER_CU")) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_idct_colour_fast, K4_THREADS, 0) == hipSuccess && nb > 0) ctx->k4_wgs_per_cu = nb;
+        if (const char* s = std::getenv("KPEG_K4_WGS_PER_CU")) {
             const int v = std::atoi(s);
-            if (v > 0) ctx->k4_waves_per_cu = v;
+            if (v > 0) ctx->k4_wgs_per_cu = v;
         }
-        if (std::getenv("KPEG_DEBUG")) std::fprintf(stderr, "kpeg_hip: K4 wavefronts per CU: %d (occupancy query %d)\n", ctx->k4_waves_per_cu, nb);
+        if (std::getenv("KPEG_DEBUG")) std::fprintf(stderr, "kpeg_hip: K4 workgroups per CU: %d (occupancy query %d), %d wavefronts each\n", ctx->k4_wgs_per_cu, nb, K4_WAVES);
     }
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return fail("hipStreamCreate", e);
@@ -392,9 +392,10 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
             p.tiles_w_magic = d > 1 ? (uint32_t)((((uint64_t)1 << (32 + sft)) + d - 1) / d) : 0;
             p.tiles_w_shift = sft;
         }
-        const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)ctx->k4_waves_per_cu;  // one wavefront per workgroup
-        const uint32_t grid = p.ntiles < resident ? p.ntiles : resident;
-        hipLaunchKernelGGL(k_idct_colour_fast, dim3(grid), dim3(64), 0, ctx->stream, p, qt);
+        const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)ctx->k4_wgs_per_cu;
+        const uint32_t want = (p.ntiles + K4_WAVES - 1) / K4_WAVES;   // at least a tile per wavefront
+        const uint32_t grid = want < resident ? want : resident;
+        hipLaunchKernelGGL(k_idct_colour_fast, dim3(grid), dim3(K4_THREADS), 0, ctx->stream, p, qt);
     }
     HIPCHK(ctx, hipGetLastError());
     return KPEG_HIP_OK;
@@ -836,3 +837,12 @@ extern "C" int kpeg_hip_debug_words(kpeg_hip_ctx* ctx, uint32_t* out, int n)
     for (int i = 0; i < n && i < (int)STATUS_WORDS; ++i) out[i] = ctx->status_seen[i];
     return KPEG_HIP_OK;
 }
+
+#ifdef KPEG_K4_STAMP
+// diagnostic build only (tools/k4_clock.py): per-wavefront start/end stamps of the last K4 launch
+extern "C" int kpeg_hip_debug_k4_stamps(unsigned long long* out, int n)
+{
+    if (n > 8192 * 4) n = 8192 * 4;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kpeg_dev::g_k4_stamp), (size_t)n * 8) == hipSuccess ? 0 : -2;
+}
+#endif

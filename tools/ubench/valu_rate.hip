@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long lo
     float2v b0 = {a0, a1}, b1 = {a1, a2}, b2 = {a2, a3}, b3 = {a3, a0};
     float c0 = 1.0001f;
     float2v c1 = {0.9999f, 1.0001f};
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (WHICH == 0) { BODY("v_fma_f32 %0, %0, %8, %1") }
     if (WHICH == 1) { BODY("v_pk_fma_f32 %4, %4, %9, %5") }
@@ -71,8 +72,12 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, unsigned long lo
     if (WHICH == 39) { BODY("v_sub_f32_e64 %0, %8, |%1|") }
     if (WHICH == 40) { BODY("v_max_f32_e64 %0, |%0|, %1") }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + b0.x + b1.y + b2.x + b3.y;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) {
+        cyc[blockIdx.x] = t1 - t0;
+        cyc[gridDim.x + blockIdx.x] = r1 - r0;   // s_memrealtime: constant 100 MHz
+    }
 }
 
 template <int WHICH>
@@ -82,7 +87,7 @@ void run(const char* name, int wavesPerSimd)
     float* out;
     unsigned long long* cyc;
     hipMalloc(&out, (size_t)ncu * wavesPerSimd * 256 * 4);
-    hipMalloc(&cyc, (size_t)ncu * wavesPerSimd * 8);
+    hipMalloc(&cyc, (size_t)ncu * wavesPerSimd * 8 * 2);
     hipLaunchKernelGGL(k<WHICH>, dim3(ncu * wavesPerSimd), dim3(256), 0, 0, 10, out, cyc);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
@@ -94,16 +99,19 @@ void run(const char* name, int wavesPerSimd)
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(ncu * wavesPerSimd);
+    std::vector<unsigned long long> h(ncu * wavesPerSimd * 2);
     hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
-    double avg = 0;
-    for (auto v : h) avg += (double)v;
-    avg /= h.size();
+    double avg = 0, real = 0;
+    const size_t nb = h.size() / 2;
+    for (size_t i = 0; i < nb; ++i) avg += (double)h[i], real += (double)h[nb + i];
+    avg /= nb;
+    real /= nb;
     const double n = (double)iters * 32;  // instructions per wave
     // s_memtime ticks = shader cycles; all W waves of a SIMD run concurrently, so per-SIMD
     // throughput cost = wave cycles / (instructions of one wave * W)
-    printf("%-28s W=%d  wave-cycles/instr %.2f  SIMD-cycles/instr %.2f  (kernel %.3f ms)\n", name, wavesPerSimd, avg / n,
-           avg / n / wavesPerSimd, ms);
+    // shader clock while this loop ran = s_memtime ticks / s_memrealtime ticks x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+    printf("%-28s W=%d  wave-cycles/instr %.2f  SIMD-cycles/instr %.2f  (kernel %.3f ms)  clock %.0f MHz  ns/instr/SIMD %.3f\n", name, wavesPerSimd, avg / n,
+           avg / n / wavesPerSimd, ms, avg / real * 100.0, real * 10.0 / n / wavesPerSimd);
     hipFree(out);
     hipFree(cyc);
 }

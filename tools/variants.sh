@@ -3,7 +3,7 @@
 #   tools/variants.sh NAME="-DX=1 -DY" NAME2="..."     then on the GPU box: tools/ablate_full.sh
 set -e
 cd "$(dirname "$0")/.."
-rm -rf build/ablate; mkdir -p build/ablate
+rm -rf build/ablate; mkdir -p build/ablate; cp build/keep/*.so build/ablate/ 2>/dev/null || true   # reference builds kept from earlier trees
 n=0
 for spec in "$@"; do
   name=${spec%%=*}; defs=${spec#*=}; [ "$defs" = "$spec" ] && defs=""
