@@ -9,12 +9,17 @@ the achieved HBM GB/s of the IDCT+colour kernel (K4) against the MI355X peak.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one full on-device decode (K0 unstuff, K1 sync, scan, K2 write, K4 IDCT+colour)
-of one image.  N > 1: weak scaling by row stripes -- the image is 7680 x (4320*N) with one
-restart interval per MCU row; rank r decodes MCU rows [540 r, 540 (r+1)) from the bytes of its
-own restart intervals, no data-path collective.  The RCCL gather of the RGB stripes to rank 0
-(the path's one exchange step) is timed separately and reported in the "gather" object; it is
-not part of `value` ("Multi-GPU").
+One step = one full on-device decode (K0 unstuff, K1 sync, scan, K2 write, K4 IDCT+colour).
+  N = 1   the headline: one 7680x4320 reference-compatible image (no restart markers), BASELINE config 3.
+  N > 1   BASELINE config 5, strong scaling: ONE 16384x16384 image with a restart interval per MCU row; rank r
+          decodes MCU rows [2048 r / N, 2048 (r+1) / N) from the bytes of its own restart intervals, no data-path
+          collective; `value` = the whole image's pixels / the slowest rank's time, stripes resident in the HBM of
+          the GPU that decoded them.  The gather of the stripes to rank 0 (the path's one exchange step: RCCL
+          send/recv over xGMI, overlapped with the decode band by band) is timed as decode + gather in the
+          "gather" object and `value_incl_gather`.  (--weak: the former weak-scaling mode, a 7680x4320 stripe per
+          rank; --image16k: config 5's image on one GPU.)
+Every rank hashes the pixels its timed loop produced against SHA-256s of libKPEG's own decoder's output
+(tests/golden/manifest_large.json): "verified".
 
 The JSON line also carries
   roofline     K4: 9 algorithmic bytes per pixel (6 B int16 coefficients in + 3 B RGB out)
@@ -71,6 +76,18 @@ def pinned_rgb_sha(w, h, world, rank, restart_stripe):
         g = m.get("synth", {}).get("%dx%d_seed%d" % (w, h, SEED))
         return g["rgb_sha256"] if g and (g["quality"], g["sigma"]) == (QUALITY, SIGMA) else None
     return None
+
+
+def pinned_stripe_shas(iw, ih, world, rank):
+    """SHA-256s of the eighth-stripes of the 16384x16384 restart-interval image that make up this rank's rows."""
+    mf = os.path.join(ROOT, "tests", "golden", "manifest_large.json")
+    if not os.path.exists(mf) or 8 % world:
+        return None
+    g = json.load(open(mf)).get("dri16k")
+    if not g or (g["width"], g["height"], g["seed"], g["quality"], g["sigma"]) != (iw, ih, SEED, QUALITY, SIGMA):
+        return None
+    per = 8 // world
+    return g["stripe8_rgb_sha256"][rank * per:(rank + 1) * per]
 
 
 def cpu_baseline(sample_w=3840, sample_h=2160):
@@ -166,8 +183,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=W8K)
-    ap.add_argument("--height", type=int, default=H8K, help="rows per GPU")
+    ap.add_argument("--width", type=int, default=None, help="image width (default: 7680, or 16384 for the sharded image)")
+    ap.add_argument("--height", type=int, default=None, help="image height (default: 4320, or 16384 for the sharded image; --weak: rows per GPU)")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: weak scaling instead of BASELINE config 5 -- every rank decodes a 7680x4320 stripe of a 7680 x (4320 N) image")
+    ap.add_argument("--image16k", action="store_true",
+                    help="N=1: decode config 5's 16384x16384 restart-interval image on one GPU (the N>1 runs' workload) instead of the 8K headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
@@ -213,21 +234,34 @@ def main():
     if args.batch:
         return bench_batch(args, torch, K)
 
-    W, H = args.width, args.height
+    # ---- workload --------------------------------------------------------------------------------------------
+    #   N = 1            the headline: one 7680x4320 reference-compatible image (BASELINE config 3)
+    #   N > 1            BASELINE config 5, strong scaling: ONE 16384x16384 image with a restart interval per MCU row,
+    #                    rank r decodes MCU rows [r*2048/N, (r+1)*2048/N) from the bytes of its own restart intervals
+    #   N > 1, --weak    every rank a 7680x4320 stripe of a 7680 x (4320 N) image
+    # W x H is what THIS rank decodes, IW x IH the whole image.
+    strong = (world > 1 and not args.weak) or args.image16k
+    if strong:
+        IW, IH = args.width or 16384, args.height or 16384
+        if (IH // 8) % world:
+            raise SystemExit("bench.py: %d MCU rows do not split evenly over %d ranks" % (IH // 8, world))
+        W, H = IW, IH // world
+    else:
+        W, H = args.width or W8K, args.height or H8K
+        IW, IH = W, H * world
     mw, mh = W // 8, H // 8
-    # ---- input: this rank's stripe of the (virtual) W x (H*world) image -------------------
-    if world == 1 and not args.restart_stripe:
+    if world == 1 and not args.restart_stripe and not strong:
         data = synth_jpeg(W, H)
         rc, frame, scan = K.host_parse(data)
         assert rc == K.DECODE_DONE, rc
         first_row, rows = 0, mh
     else:
         # restart interval = one MCU row; the stripe is generated directly (restart intervals are
-        # independent), parsed with the DRI extension, decoded as rows [rank*mh, (rank+1)*mh)
+        # independent), parsed with the DRI extension, decoded as rows [rank*mh, (rank+1)*mh) of the whole image
         data = synth_jpeg(W, H, y0=rank * H, restart_interval=mw)
         rc, frame, scan = K.host_parse(data, allow_dri=True)
         assert rc == K.DECODE_DONE, rc
-        frame.height = H * world
+        frame.height = IH
         first_row, rows = rank * mh, mh
 
     ctx = K.Context(local_rank)
@@ -281,12 +315,24 @@ def main():
     # (tests/golden/make_golden_large.py, build container); None = this workload has no pinned hash
     verified = None
     if not args.idct_only and args.idct_mode == 0:
-        want_sha = pinned_rgb_sha(W, H, world, rank, args.restart_stripe)
+        import hashlib
+        want_sha = pinned_rgb_sha(W, H, world, rank, args.restart_stripe or strong)
+        parts = pinned_stripe_shas(IW, IH, world, rank) if strong else None
         if want_sha is not None:
-            import hashlib
             verified = hashlib.sha256(d_rgb.cpu().numpy().tobytes()).hexdigest() == want_sha
-            if not verified:
-                raise SystemExit("bench.py: rank %d decoded pixels that differ from the reference's (SHA-256 mismatch)" % rank)
+        elif parts is not None:
+            # this rank's rows are whole eighths of the image: each against the reference's per-interval decode
+            host = d_rgb.cpu().numpy()
+            per = host.shape[0] // len(parts)
+            verified = all(hashlib.sha256(host[i * per:(i + 1) * per].tobytes()).hexdigest() == parts[i] for i in range(len(parts)))
+            del host
+        if verified is False:
+            raise SystemExit("bench.py: rank %d decoded pixels that differ from the reference's (SHA-256 mismatch)" % rank)
+        if world > 1:
+            # every rank's verdict: all True -> True, any unpinned -> None
+            flags = [None] * world
+            dist.all_gather_object(flags, verified)
+            verified = None if any(f is None for f in flags) else all(flags)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -360,35 +406,80 @@ def main():
                   "scan_bytes": int(sd_scan.numel()), "ms_per_step": round(sms, 4), "value": round(sw * sh / (sms * 1e-3) / 1e6, 2),
                   "unit": "Mpixels/s"}
 
-    # ---- gather of the stripes to rank 0 (the path's one exchange step), timed apart ----------
+    # ---- decode + gather of the stripes to rank 0 (the path's one exchange step), timed apart --------------------
+    # Every rank decodes its stripe as two bands of whole MCU rows; a band leaves for rank 0 (point-to-point send over
+    # RCCL/xGMI, straight into its rows of the root's image) as soon as it is decoded, while the next band decodes.
     gather = None
     if world > 1 and not args.no_gather:
-        g_src = d_rgb.cpu() if args.rehearse else d_rgb
-        glist = [torch.empty_like(g_src) for _ in range(world)] if rank == 0 else None
+        nb = 2 if rows >= 2 else 1
+        bands = K.stripe_ranges(scan, rows, mw, frame.restart_interval, nb)   # (first row in the stripe, rows, byte range)
+        band_scans = [d_scan[b0:b1].clone() for (_, _, b0, b1) in bands]      # own allocations: 16-byte aligned for K0
+        full = torch.empty((IH, IW, 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
+        mine = full[rank * H:(rank + 1) * H] if rank == 0 else d_rgb
+        host_bufs = {}
+
+        def one_round():
+            reqs = []
+            if rank == 0:
+                for src in range(1, world):
+                    for (r0, nr, _, _) in bands:
+                        dst_rows = full[src * H + r0 * 8: src * H + (r0 + nr) * 8]
+                        if args.rehearse:
+                            hb = host_bufs.setdefault((src, r0), torch.empty(dst_rows.shape, dtype=torch.uint8))
+                            reqs.append((dist.irecv(hb, src=src), hb, dst_rows))
+                        else:
+                            reqs.append((dist.irecv(dst_rows, src=src), None, None))
+            for bi, (r0, nr, _, _) in enumerate(bands):
+                out_rows = mine[r0 * 8:(r0 + nr) * 8]
+                ctx.decode_stripe_dev(frame, band_scans[bi].data_ptr(), band_scans[bi].numel(), first_row + r0, nr, out_rows.data_ptr())
+                if rank != 0:
+                    if args.rehearse:
+                        ctx.sync()
+                        reqs.append((dist.isend(out_rows.cpu(), dst=0), None, None))
+                    else:
+                        reqs.append((dist.isend(out_rows, dst=0), None, None))   # behind this band's kernels; the next band decodes meanwhile
+            for (w, hb, dst_rows) in reqs:
+                w.wait()
+                if hb is not None:
+                    dst_rows.copy_(hb)
+            torch.cuda.synchronize()
+
         for _ in range(2):
-            dist.gather(g_src, glist, dst=0)
+            one_round()
+        ctx.sync()
         barrier()
         g0 = time.perf_counter()
-        nrep = 5
+        nrep = max(3, min(args.steps, 10))
         for _ in range(nrep):
-            dist.gather(g_src, glist, dst=0)
-        torch.cuda.synchronize()
+            one_round()
         dist.barrier()
         gms = (time.perf_counter() - g0) / nrep * 1e3
+        ctx.sync()
         t = torch.tensor([gms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gms = float(t.item())
-        if rank == 0 and os.environ.get("KPEG_BENCH_VERIFY"):
-            # rehearsal check: the gathered image equals the oracle's decode of the same virtual image
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import kpeg_testlib as T
-            full = torch.cat([g.cpu() for g in glist], 0).numpy()
-            want = np.concatenate([T.oracle_decode_rst(synth_jpeg(W, H, y0=r * H, restart_interval=mw), mw, 16)[0] for r in range(world)], 0)
-            assert np.array_equal(full, want), "gathered stripes differ from the oracle"
-            print("VERIFY_OK gathered %dx%d image equals the oracle" % (W, H * world), file=sys.stderr)
+        gathered_ok = None
+        if rank == 0:
+            import hashlib
+            shas = pinned_stripe_shas(IW, IH, 1, 0) if strong else None
+            if shas is not None:
+                host = full.cpu().numpy()
+                per = IH // 8
+                gathered_ok = all(hashlib.sha256(host[i * per:(i + 1) * per].tobytes()).hexdigest() == shas[i] for i in range(8))
+                del host
+                if not gathered_ok:
+                    raise SystemExit("bench.py: the gathered image differs from the reference's (SHA-256 mismatch)")
+            if os.environ.get("KPEG_BENCH_VERIFY"):
+                # rehearsal check on sizes without a pinned hash: the gathered image equals the oracle's decode
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import kpeg_testlib as T
+                want = np.concatenate([T.oracle_decode_rst(synth_jpeg(W, H, y0=r * H, restart_interval=mw), mw, 16)[0] for r in range(world)], 0)
+                assert np.array_equal(full.cpu().numpy(), want), "gathered stripes differ from the oracle"
+                print("VERIFY_OK gathered %dx%d image equals the oracle" % (IW, IH), file=sys.stderr)
         gbytes = (world - 1) * d_rgb.numel()
-        gather = {"ms": round(gms, 4), "GB/s_into_root": round(gbytes / gms / 1e6, 2), "bytes": gbytes,
-                  "collective": "torch.distributed.gather over RCCL (grouped send/recv), RGB stripes -> rank 0"}
+        gather = {"ms_decode_and_gather": round(gms, 4), "bytes_into_root": gbytes, "bands_per_rank": nb, "verified": gathered_ok,
+                  "how": "each rank decodes its stripe in %d bands; a band is sent to rank 0 (RCCL send/recv over xGMI, into its rows of the "
+                         "root's image) while the next band decodes" % nb}
 
     if rank == 0:
         pixels_per_step = W * H * world
@@ -398,7 +489,7 @@ def main():
         alg_bytes = 9.0 * W * H  # per launch: this rank's stripe
         traffic = None
         tf = os.path.join(ROOT, "profiles", "k4_traffic.json")
-        if world == 1 and (W, H) == (W8K, H8K) and os.path.exists(tf):
+        if world == 1 and (W, H) == (W8K, H8K) and not strong and os.path.exists(tf):
             # HBM bytes per launch from the PMC passes committed under profiles/ (same kernel, same workload;
             # counters cannot be read from inside this process)
             traffic = json.load(open(tf)).get("traffic_bytes")
@@ -411,12 +502,12 @@ def main():
         out = {
             "metric": "Mpixels/s decoded (JFIF->RGB) + achieved HBM GB/s, 8K 4:4:4 baseline",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("K4 only, " if args.idct_only else "") +
                        "%dx%d 4:4:4 baseline JPEG q%d, seed %d, %s" % (
-                           W, H * world, QUALITY, SEED,
-                           "no restart markers, full on-device Huffman + IDCT" if world == 1 and not args.restart_stripe else
+                           IW, IH, QUALITY, SEED,
+                           "no restart markers, full on-device Huffman + IDCT" if world == 1 and not args.restart_stripe and not strong else
                            "restart interval = 1 MCU row, %d row stripes of %d rows, one per GPU" % (world, H)),
                        "scan_bytes_per_gpu": int(d_scan.numel()), "pixels_per_step": pixels_per_step},
             "verified": verified,   # the timed loop's output == the reference decoder's pixels (SHA-256), None = not pinned
@@ -441,7 +532,7 @@ def main():
             out["stress"] = stress
         if gather:
             out["gather"] = gather
-            out["value_incl_gather"] = round(pixels_per_step / ((ms_per_step + gather["ms"]) * 1e-3) / 1e6, 2)
+            out["value_incl_gather"] = round(pixels_per_step / (gather["ms_decode_and_gather"] * 1e-3) / 1e6, 2)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

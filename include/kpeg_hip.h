@@ -123,6 +123,24 @@ int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8
 int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_frame* frame, const uint8_t* const* scans,
                           const size_t* scan_lens, uint8_t* const* rgbs);
 
+/* Row-stripe sharding of ONE image over several GPUs from a single host thread (BASELINE config 5; the reference
+ * has no counterpart: it rejects DRI, src/Decoder.cpp:58-74, and is single-threaded).  ctxs[g] is a context created
+ * on the g-th GPU to use (two contexts on one GPU also work); frame->restart_interval must be non-zero and whole
+ * MCU rows must start on restart-interval boundaries.  `scan` is the whole entropy-coded segment in host memory: it
+ * is cut at its RSTn markers, stripe g (MCU rows [g*R, (g+1)*R), R = ceil(rows / ngpu)) is uploaded to ctxs[g]'s
+ * GPU and decoded there with kpeg_hip_decode_stripe_dev, all GPUs concurrently.
+ *   kpeg_hip_decode_sharded      rgb_root = host buffer of height*width*3 bytes: every GPU downloads its own rows
+ *                                straight into it over its own PCIe link (no gather through one GPU).
+ *   kpeg_hip_decode_sharded_dev  d_rgb_root = device buffer of height*width*3 bytes on ctxs[0]'s GPU: the other
+ *                                GPUs' stripes arrive there by peer copies over xGMI (hipMemcpyPeerAsync), each as
+ *                                soon as its stripe is decoded.
+ * Both return after everything has arrived; the first error of any stripe is returned (kpeg_hip_last_error(ctxs[0])
+ * names the stripe). */
+int kpeg_hip_decode_sharded(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len,
+                            uint8_t* rgb_root);
+int kpeg_hip_decode_sharded_dev(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len,
+                                uint8_t* d_rgb_root);
+
 /* ---- device-resident entry points (asynchronous on the context's stream) --------------- */
 /* All pointers are device pointers.  Errors found by kernels surface at kpeg_hip_sync(). */
 int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const int16_t* d_coef, uint8_t* d_rgb);

@@ -56,7 +56,7 @@ EXPORTS = [
     "kpeg_hip_set_stream", "kpeg_hip_sync", "kpeg_hip_set_profiling", "kpeg_hip_get_timings",
     "kpeg_hip_idct_colour", "kpeg_hip_decode_scan", "kpeg_hip_decode_batch", "kpeg_hip_decode_batch_dev",
     "kpeg_hip_idct_colour_dev", "kpeg_hip_decode_scan_dev", "kpeg_hip_decode_stripe_dev",
-    "kpeg_hip_entropy_decode_dev", "kpeg_hip_set_idct_mode",
+    "kpeg_hip_entropy_decode_dev", "kpeg_hip_set_idct_mode", "kpeg_hip_decode_sharded", "kpeg_hip_decode_sharded_dev",
 ]
 
 _lib = None
@@ -111,6 +111,8 @@ def _declare(L):
     L.kpeg_hip_decode_scan_dev.argtypes = [vp, FP, vp, sz, vp]
     L.kpeg_hip_decode_stripe_dev.argtypes = [vp, FP, vp, sz, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.kpeg_hip_entropy_decode_dev.argtypes = [vp, FP, vp, sz, vp]
+    L.kpeg_hip_decode_sharded.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
+    L.kpeg_hip_decode_sharded_dev.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
     return L
 
 
@@ -208,6 +210,20 @@ class Context:
     def entropy_decode_dev(self, frame, d_scan, scan_len, d_coef):
         self._chk(self.lib.kpeg_hip_entropy_decode_dev(self._h, ctypes.byref(frame), ctypes.c_void_p(d_scan), scan_len,
                                                        ctypes.c_void_p(d_coef)))
+
+
+def decode_sharded(ctxs, frame, scan, d_rgb_root=None):
+    """One image over len(ctxs) GPUs from this process (kpeg_hip_decode_sharded / _dev).  scan: host bytes of the whole
+    DRI scan.  d_rgb_root: device pointer on ctxs[0]'s GPU, or None for a host result (returned as an array)."""
+    lib = ctxs[0].lib
+    scan = np.ascontiguousarray(np.frombuffer(scan, np.uint8) if not isinstance(scan, np.ndarray) else scan)
+    hs = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    if d_rgb_root is None:
+        rgb = np.empty((frame.height, frame.width, 3), np.uint8)
+        ctxs[0]._chk(lib.kpeg_hip_decode_sharded(hs, len(ctxs), ctypes.byref(frame), scan.ctypes.data, scan.size, rgb.ctypes.data))
+        return rgb
+    ctxs[0]._chk(lib.kpeg_hip_decode_sharded_dev(hs, len(ctxs), ctypes.byref(frame), scan.ctypes.data, scan.size, ctypes.c_void_p(d_rgb_root)))
+    return None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -428,7 +428,13 @@ namespace kpeg
             return ERROR;
         }
         std::vector<UInt8> rgb( (std::size_t)w * h * 3 );
-        const int rc = kpeg_hip_decode_scan( ctx, &f, scan_.data(), scan_.size(), rgb.data() );
+        int rc;
+        const std::vector<kpeg_hip_ctx*>& many = f.restart_interval ? hip::contexts( &why ) : std::vector<kpeg_hip_ctx*>();
+        if ( many.size() > 1 && ( w / 8 ) % f.restart_interval == 0 )   // every MCU row starts a restart interval
+            // extension (the reference rejects DRI): a restart-interval image goes over $KPEG_HIP_DEVICES GPUs as row stripes
+            rc = kpeg_hip_decode_sharded( many.data(), (int)many.size(), &f, scan_.data(), scan_.size(), rgb.data() );
+        else
+            rc = kpeg_hip_decode_scan( ctx, &f, scan_.data(), scan_.size(), rgb.data() );
         if ( rc != KPEG_HIP_OK )
         {
             LOG(Logger::Level::ERROR) << "[ FATAL ] GPU decode failed: " << kpeg_hip_strerror( rc ) << ": " << kpeg_hip_last_error( ctx ) << std::endl;

@@ -2,6 +2,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <string>
 
 namespace kpeg
 {
@@ -36,6 +37,45 @@ namespace kpeg
             if ( !h.ctx && why )
                 *why = h.error;
             return h.ctx;
+        }
+
+        const std::vector<kpeg_hip_ctx*>& contexts( std::string* why )
+        {
+            struct Many
+            {
+                std::vector<kpeg_hip_ctx*> all;
+                std::string error;
+                ~Many() { for ( std::size_t i = 1; i < all.size(); ++i ) kpeg_hip_destroy( all[i] ); }   // [0] belongs to context()
+            };
+            static Many m;
+            static std::once_flag once;
+            std::call_once( once, [] {
+                kpeg_hip_ctx* first = context( &m.error );
+                if ( !first )
+                    return;
+                m.all.push_back( first );
+                int n = 1, dev0 = 0;
+                if ( const char* e = std::getenv( "KPEG_HIP_DEVICES" ) )
+                    n = std::atoi( e );
+                if ( const char* e = std::getenv( "KPEG_HIP_DEVICE" ) )
+                    dev0 = std::atoi( e );
+                for ( int i = 1; i < n; ++i )
+                {
+                    kpeg_hip_ctx* c = nullptr;
+                    const int rc = kpeg_hip_create( &c, dev0 + i );
+                    if ( rc != KPEG_HIP_OK )
+                    {
+                        m.error = std::string( "kpeg_hip_create failed on device " ) + std::to_string( dev0 + i ) + ": " + kpeg_hip_strerror( rc );
+                        for ( std::size_t k = 1; k < m.all.size(); ++k ) kpeg_hip_destroy( m.all[k] );
+                        m.all.clear();
+                        return;
+                    }
+                    m.all.push_back( c );
+                }
+            } );
+            if ( m.all.empty() && why )
+                *why = m.error;
+            return m.all;
         }
     }
 }

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <algorithm>
 
@@ -811,6 +812,118 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
         have_prev = true;
     }
     return download(prev, lane ^ 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One image over several GPUs, single host thread (include/kpeg_hip.h: kpeg_hip_decode_sharded).
+static int decode_sharded_impl(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_frame* f, const uint8_t* scan, size_t scan_len,
+                               uint8_t* rgb_root, bool root_is_device)
+{
+    if (!ctxs || ngpu <= 0 || !ctxs[0]) return KPEG_HIP_E_ARG;
+    kpeg_hip_ctx* root = ctxs[0];
+    int rc = check_frame(root, f);
+    if (rc) return rc;
+    if (!scan || !scan_len || !rgb_root) return KPEG_HIP_E_ARG;
+    for (int g = 0; g < ngpu; ++g)
+        if (!ctxs[g]) return KPEG_HIP_E_ARG;
+    const uint32_t mw = f->width / 8, mh = f->height / 8;
+    if (ngpu > 1 && f->restart_interval == 0) {
+        root->last_error = "a stream without restart markers is one serial bit string: it cannot be sharded";
+        return KPEG_HIP_E_UNSUPPORTED;
+    }
+    // stripes of whole MCU rows; every stripe must start on a restart-interval boundary
+    const uint32_t rows_per = (mh + (uint32_t)ngpu - 1) / (uint32_t)ngpu;
+    struct Stripe { uint32_t r0 = 0, nr = 0; size_t b0 = 0, b1 = 0; };
+    std::vector<Stripe> st((size_t)ngpu);
+    if (ngpu == 1) {
+        st[0].r0 = 0, st[0].nr = mh, st[0].b0 = 0, st[0].b1 = scan_len;
+    } else {
+        // RSTn positions in the still-stuffed scan: FF D0..D7 cannot occur inside entropy-coded data
+        std::vector<size_t> rst;
+        for (size_t i = 0; i + 1 < scan_len; ++i)
+            if (scan[i] == 0xFF && scan[i + 1] >= 0xD0 && scan[i + 1] <= 0xD7) rst.push_back(i);
+        const uint64_t nint = ((uint64_t)mw * mh + f->restart_interval - 1) / f->restart_interval;
+        if (rst.size() + 1 != nint) {
+            root->last_error = "restart markers do not match the restart interval";
+            return KPEG_HIP_E_STREAM;
+        }
+        for (int g = 0; g < ngpu; ++g) {
+            Stripe& s = st[(size_t)g];
+            s.r0 = std::min((uint32_t)g * rows_per, mh);
+            s.nr = std::min(rows_per, mh - s.r0);
+            if (!s.nr) continue;
+            if (((uint64_t)s.r0 * mw) % f->restart_interval) {
+                root->last_error = "stripe boundaries must coincide with restart intervals";
+                return KPEG_HIP_E_ARG;
+            }
+            const uint64_t i0 = (uint64_t)s.r0 * mw / f->restart_interval;
+            const uint64_t i1 = ((uint64_t)(s.r0 + s.nr) * mw + f->restart_interval - 1) / f->restart_interval;
+            s.b0 = i0 == 0 ? 0 : rst[i0 - 1] + 2;
+            s.b1 = i1 >= nint ? scan_len : rst[i1 - 1];
+        }
+    }
+    const size_t pitch = (size_t)f->width * 3;
+    // One host thread per GPU (a context is used by one thread at a time; different contexts are independent): upload,
+    // decode and the stripe's way to the root are enqueued on that GPU's stream and waited for there, so no GPU waits
+    // for the host to have finished enqueueing another GPU's work.
+    std::vector<int> err((size_t)ngpu, KPEG_HIP_OK);
+    auto work = [&](int g) {
+        kpeg_hip_ctx* c = ctxs[g];
+        const Stripe& s = st[(size_t)g];
+        int& e = err[(size_t)g];
+        if (!s.nr) return;
+        if (hipSetDevice(c->device) != hipSuccess) { e = KPEG_HIP_E_DEVICE; return; }
+        const size_t len = s.b1 - s.b0, sbytes = (size_t)s.nr * 8 * pitch;
+        uint8_t* const home = rgb_root + (size_t)s.r0 * 8 * pitch;   // where the stripe belongs
+        if ((e = grow(c, &c->d_scan, &c->scan_cap, len + 64))) return;
+        uint8_t* dst = home;
+        if (!(root_is_device && c->device == root->device)) {
+            if ((e = grow(c, &c->d_rgb, &c->rgb_cap, sbytes))) return;
+            dst = (uint8_t*)c->d_rgb;
+        }
+        if (hipMemcpyAsync(c->d_scan, scan + s.b0, len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { e = KPEG_HIP_E_DEVICE; return; }
+        if ((e = kpeg_hip_decode_stripe_dev(c, f, (const uint8_t*)c->d_scan, len, s.r0, s.nr, dst))) return;
+        if (dst != home) {
+            const hipError_t he = root_is_device
+                ? hipMemcpyPeerAsync(home, root->device, dst, c->device, sbytes, c->stream)   // over xGMI, behind this stripe's decode
+                : hipMemcpyAsync(home, dst, sbytes, hipMemcpyDeviceToHost, c->stream);        // this GPU's own PCIe link
+            if (he != hipSuccess) { e = KPEG_HIP_E_DEVICE; return; }
+        }
+        e = kpeg_hip_sync(c);
+    };
+    {
+        // contexts that share a GPU-side object (the same context listed twice) must not run concurrently: one thread each
+        // only for distinct contexts
+        std::vector<std::thread> th;
+        for (int g = 1; g < ngpu; ++g) {
+            bool dup = false;
+            for (int k = 0; k < g; ++k) dup = dup || ctxs[k] == ctxs[g];
+            if (dup) work(g);
+            else th.emplace_back(work, g);
+        }
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    (void)hipSetDevice(root->device);
+    for (int g = 0; g < ngpu; ++g)
+        if (err[(size_t)g]) {
+            const std::string why = ctxs[g]->last_error;   // (may be root's own: copy before it is overwritten)
+            root->last_error = "stripe " + std::to_string(g) + ": " + std::string(kpeg_hip_strerror(err[(size_t)g])) + " (" + why + ")";
+            return err[(size_t)g];
+        }
+    return KPEG_HIP_OK;
+}
+
+extern "C" int kpeg_hip_decode_sharded(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_frame* f, const uint8_t* scan, size_t scan_len,
+                                       uint8_t* rgb_root)
+{
+    return decode_sharded_impl(ctxs, ngpu, f, scan, scan_len, rgb_root, false);
+}
+
+extern "C" int kpeg_hip_decode_sharded_dev(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_frame* f, const uint8_t* scan, size_t scan_len,
+                                           uint8_t* d_rgb_root)
+{
+    return decode_sharded_impl(ctxs, ngpu, f, scan, scan_len, d_rgb_root, true);
 }
 
 // test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default),

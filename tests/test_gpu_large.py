@@ -125,3 +125,39 @@ def test_16k_restart_image_whole_and_as_8_stripes(ctx):
         ctx.decode_stripe_dev(frame, sl.data_ptr(), sl.numel(), r0, nr, d_rgb[r0 * 8:].data_ptr())
         ctx.sync()
         assert sha(d_rgb[r0 * 8:(r0 + nr) * 8].cpu().numpy().tobytes()) == g["stripe8_rgb_sha256"][s], s
+
+
+def test_sharded_c_entry_with_two_contexts_on_one_gpu(ctx):
+    """kpeg_hip_decode_sharded / _dev: ONE process, one context per GPU, host threads inside.  Rehearsed with two and
+    three contexts on GPU 0 (the stripes then run concurrently on one device): the host-destination form (every GPU
+    downloads its own rows) and the device-destination form (peer copies into the root GPU's buffer) must both equal the
+    oracle, for a restart interval of one MCU row and of a quarter row."""
+    import torch
+    import libkpeg_amd as K
+    others = [K.Context(0), K.Context(0)]
+    try:
+        for (w, h, interval) in ((1024, 520, 128), (512, 264, 16)):
+            data = T.synth_jpeg(w, h, seed=61, restart_interval=interval, sigma=9.0)
+            want, p, _ = T.oracle_decode_rst(data, interval)
+            rc, frame, scan = K.host_parse(data, allow_dri=True)
+            assert rc == K.DECODE_DONE
+            for n in (1, 2, 3):
+                cs = [ctx] + others[: n - 1]
+                got = K.decode_sharded(cs, frame, scan)
+                assert np.array_equal(got, want), (w, h, interval, n, "host")
+                d = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                K.decode_sharded(cs, frame, scan, d_rgb_root=d.data_ptr())
+                assert np.array_equal(d.cpu().numpy(), want), (w, h, interval, n, "device")
+        # a stream without restart markers cannot be sharded
+        data = T.synth_jpeg(256, 128, seed=62)
+        rc, frame, scan = K.host_parse(data)
+        with pytest.raises(K.KpegError) as ei:
+            K.decode_sharded([ctx, others[0]], frame, scan)
+        assert ei.value.code == K.E_UNSUPPORTED
+        # ... one context is just a decode
+        st, want1 = T.oracle_decode(data)
+        assert np.array_equal(K.decode_sharded([ctx], frame, scan), want1)
+    finally:
+        for c in others:
+            c.close()
