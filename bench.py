@@ -224,6 +224,9 @@ def main():
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # one explicit stream for torch's ops and the decoder's kernels alike (the default stream's handle is NULL, which the
+    # C ABI reads as "the context's own stream": work on that would not be ordered with torch's)
+    torch.cuda.set_stream(torch.cuda.Stream())
     if world > 1:
         if args.rehearse:
             dist.init_process_group(backend="gloo")

@@ -90,7 +90,8 @@ def _declare(L):
     vp, c_int, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     FP = ctypes.POINTER(Frame)
     L.kpeg_hip_abi_version.restype = c_int
-    L.kpeg_hip_build_hash.restype = ctypes.c_char_p
+    if hasattr(L, "kpeg_hip_build_hash"):
+        L.kpeg_hip_build_hash.restype = ctypes.c_char_p
     L.kpeg_hip_create.argtypes = [ctypes.POINTER(vp), c_int]
     L.kpeg_hip_destroy.argtypes = [vp]
     L.kpeg_hip_destroy.restype = None
@@ -111,8 +112,9 @@ def _declare(L):
     L.kpeg_hip_decode_scan_dev.argtypes = [vp, FP, vp, sz, vp]
     L.kpeg_hip_decode_stripe_dev.argtypes = [vp, FP, vp, sz, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.kpeg_hip_entropy_decode_dev.argtypes = [vp, FP, vp, sz, vp]
-    L.kpeg_hip_decode_sharded.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
-    L.kpeg_hip_decode_sharded_dev.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
+    if hasattr(L, "kpeg_hip_decode_sharded"):   # (reference builds of earlier trees kept for A/B runs lack the newer entries)
+        L.kpeg_hip_decode_sharded.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
+        L.kpeg_hip_decode_sharded_dev.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
     return L
 
 
@@ -144,7 +146,14 @@ class Context:
 
     # -- knobs
     def set_stream(self, hip_stream):
-        self._chk(self.lib.kpeg_hip_set_stream(self._h, ctypes.c_void_p(hip_stream)))
+        """hip_stream: a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream.  PyTorch's default stream reports
+        handle 0 = the legacy default stream, which the C ABI spells KPEG_HIP_STREAM_LEGACY (its NULL means "the context's
+        own stream", which is NOT ordered with default-stream work): mapped here, so that tensors produced by torch ops just
+        before a call are complete when the kernels read them."""
+        self._chk(self.lib.kpeg_hip_set_stream(self._h, ctypes.c_void_p(hip_stream if hip_stream else 1)))
+
+    def use_own_stream(self):
+        self._chk(self.lib.kpeg_hip_set_stream(self._h, ctypes.c_void_p(0)))
 
     def set_profiling(self, on):
         self._chk(self.lib.kpeg_hip_set_profiling(self._h, int(bool(on))))

@@ -98,8 +98,9 @@ constexpr int POOL_SUBS = KPEG_POOL_SUBS;             // second-level tables sha
 //   [22:16] coefficient advance: AC run + 1, EOB / no such code 64, DC 65 (>= 64 ends the table's turn)
 //   [23] no such code                    [24] DC symbol with a run nibble (outside the contract)
 //   [25] DC symbol other than 0x00: the block keeps its AC terms (quirk Q1)
+//   [26] AC symbol that carries a non-zero coefficient (category > 0): one record of the compact coefficient stream
 //   [31] code longer than LUT_BITS: [15:0] = second-level table in the pool, E_SEARCH = none left
-constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_KEEP = 1u << 25, E_LONG = 1u << 31;
+constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_KEEP = 1u << 25, E_REC = 1u << 26, E_LONG = 1u << 31;
 constexpr uint32_t E_SEARCH = 0xFFFFu;
 
 __host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool isdc)
@@ -107,7 +108,7 @@ __host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool 
     const uint32_t cat = sym & 15, run = sym >> 4;
     const uint32_t kadv = isdc ? 65u : (sym == 0 ? 64u : run + 1);
     return (len + cat) | (len << 5) | (cat << 10) | (isdc ? E_ISDC : 0u) | (sym == 0 ? E_ZERO : 0u) | (kadv << 16) |
-           ((isdc && run) ? E_DCRUN : 0u) | ((isdc && sym != 0) ? E_KEEP : 0u);
+           ((isdc && run) ? E_DCRUN : 0u) | ((isdc && sym != 0) ? E_KEEP : 0u) | ((!isdc && cat != 0) ? E_REC : 0u);
 }
 // no such code: keep moving by 16 bits (only a speculative decode or a corrupt stream gets here;
 // the reference would never leave its bit loop, Decoder.cpp:704-748)
@@ -196,6 +197,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t nsub;     // total sub-sequences
     uint32_t moved[SYNC_PASSES + 8];  // per pass >= 1: workgroups whose last exit state moved
     uint32_t total_blocks;
+    uint32_t total_rec;   // records of the compact coefficient stream (K1's count)
     uint32_t ticket;   // workgroups that have finished the chained pass
     uint32_t k0_slot[64], k0_top;   // K0's two-level ticket (restart segments: the last workgroup to finish sets the segments up)
     uint32_t k1_order;   // K1's chained pass: logical workgroup index = the order in which workgroups start (K0 clears it)
@@ -236,6 +238,7 @@ struct EntropyScratch {
     void* d_state = nullptr;    size_t state_cap = 0;   // X[nsub], Xb[2][nwg], assumed[nwg] uint64
     void* d_cnt = nullptr;      size_t cnt_cap = 0;     // cnt[nsub] int4
     void* d_wsum = nullptr;     size_t wsum_cap = 0;
+    void* d_nrec = nullptr;     size_t nrec_cap = 0;    // nrec[nsub], wrec[nwg]: record counts of the compact coefficient stream
     EntropyMeta* d_meta = nullptr;
     EntropyTables* d_tabs = nullptr;
     EntropyTables h_tabs_cached;
@@ -244,7 +247,7 @@ struct EntropyScratch {
 
 static void entropy_scratch_free(EntropyScratch* s)
 {
-    void* ps[] = {s->d_u, s->d_part, s->d_segoff, s->d_state, s->d_cnt, s->d_wsum, s->d_meta, s->d_tabs};
+    void* ps[] = {s->d_u, s->d_part, s->d_segoff, s->d_state, s->d_cnt, s->d_wsum, s->d_nrec, s->d_meta, s->d_tabs};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     *s = EntropyScratch();
@@ -263,6 +266,12 @@ struct EntropyLaunch {
     int sync_passes;   // 0 = default
     int warm;          // warm-up sub-sequences per workgroup, < 0 = default (test hook: 0 makes every workgroup guess wrong)
     int subseq = 0;    // sub-sequence size: 0 = chosen from the bit rate, else SUBSEQ_SPARSE or SUBSEQ_DENSE (test hook)
+    // compact coefficient stream instead of the dense layout (d_coef unused): see WriteArgs
+    uint32_t* d_rec = nullptr;
+    uint32_t rec_cap = 0;
+    int16_t* d_dc16 = nullptr;
+    uint32_t* d_tile_start = nullptr;
+    uint32_t ntiles = 0;
     unsigned long long spin_ticks = 0;   // bound of the waits between workgroups in 100 MHz ticks, 0 = defaults (test hook)
     uint32_t fault = 0;                  // fault injection (test hook): bit 0 K0's, bit 1 K1's workgroup 0 never publishes
     // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
@@ -341,6 +350,8 @@ __device__ void seg_setup_wg(EntropyMeta* meta, uint32_t* seg_off, uint32_t* sub
     if (nseg != expected_segs || nseg + 1 > seg_cap) {
         if (t == 0) {
             atomicOr(&status[1], 1u);  // restart markers do not match the restart interval
+            status[4] = nseg;          // (diagnostics: what was counted, what the frame says)
+            status[5] = expected_segs;
             meta->nsub = 0;
         }
         return;
@@ -488,7 +499,9 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
         // wavefront 0 looks back 64 predecessors at a time: the nearest inclusive prefix ends the walk
         const unsigned long long mine = (unsigned long long)tk | ((unsigned long long)tm << 28);
         const bool mute = (fault & 1u) && g == 0 && gridDim.x > 1;   // test hook: workgroup 0 never publishes, its successors fall back
-        if (lane == 0 && g > 0) __hip_atomic_store(&part[g], mine | LB_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (test hook, fault bit 2: nobody publishes an aggregate ahead of its prefix -- with a short bound the look-back
+        // then computes many predecessors' aggregates itself, whatever kind of chunk they are)
+        if (lane == 0 && g > 0 && !(fault & 4u)) __hip_atomic_store(&part[g], mine | LB_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t acc_k = 0, acc_m = 0;
         for (int base = (int)g - 1; base >= 0; base -= 64) {
             const int j = base - (int)lane;
@@ -765,6 +778,7 @@ __device__ __forceinline__ uint32_t state_table(const DecState& s) { return (s.c
 struct RunResult {
     uint64_t exit_state;
     int4 cnt;     // blocks started (DC symbols decoded), sums of their DC differences per component
+    uint32_t nrec;   // non-zero AC coefficients K2 will emit for this run (records of the compact coefficient stream)
 #if KPEG_SYNC_STATS
     uint32_t iters;
 #endif
@@ -779,7 +793,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
     const uint32_t cfirst = s.k == 0 ? s.c : (s.c == 2 ? 0u : s.c + 1);  // component of the first block started here
     // DC sums rotate with the blocks: the current block's component adds into the slot that moves to the back
     int s0 = 0, s1 = 0, s2 = 0;
-    uint32_t nb = 0;
+    uint32_t nb = 0, nrec = 0;
 #if KPEG_SYNC_STATS
     uint32_t iters = 0;
 #endif
@@ -789,6 +803,9 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
         const uint32_t e = lut_finish(T, tb, win, e1);
         const uint32_t kraw = k + ((e >> 16) & 127);
         const bool adv = kraw >= 64;   // this table's turn ends: DC symbol, EOB, 63rd coefficient (Decoder.cpp:759)
+        // exactly K2's condition for storing an AC coefficient, minus its check that the block lies inside the segment
+        // (K2 never emits more records than are counted here: the counts fix where every lane's records go)
+        nrec += ((e >> 26) & 1u) & q & (kraw <= 64 ? 1u : 0u);
         k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
         q = adv ? ((e >> 25) & 1u) : q;
         tb += adv ? LUT_BYTES : 0u;
@@ -810,6 +827,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
     RunResult r;
     // slot j holds component (cfirst + nb + j) mod 3
     const uint32_t rot = (cfirst + nb) % 3;
+    r.nrec = nrec;
     r.cnt.x = (int)nb;
     r.cnt.y = rot == 0 ? s0 : (rot == 1 ? s2 : s1);
     r.cnt.z = rot == 0 ? s1 : (rot == 1 ? s0 : s2);
@@ -872,7 +890,11 @@ struct SyncArgs {
     uint64_t* assumed;  // [nwg_cap] entry state each workgroup last decoded from (X_NONE: known, first of a segment)
     int4* cnt;          // [nsub_cap] (blocks started, dc sums) of the run that produced X
     int4* wsum;         // [nwg_cap] per-workgroup totals of cnt
-    uint4* coef16;      // pass 0 clears the coefficient buffer, a slice per workgroup, behind its decode
+    uint32_t* nrec;     // [nsub_cap] records (non-zero AC coefficients) of the run that produced X
+    uint32_t* wrec;     // [nwg_cap] per-workgroup totals of nrec
+    uint32_t* tile_start;  // compact coefficient stream (non-null): [ntiles + 1] first record of every K4 tile, preset to 0 here
+    uint32_t ntiles;
+    uint4* coef16;      // pass 0 clears the coefficient buffer, a slice per workgroup, behind its decode (dense layout only)
     uint64_t coef_n16;
     uint32_t* ebound;   // ... and presets K4's per-block bounds to +inf (a block K2 leaves out takes K4's exact path)
     uint32_t nblocks;
@@ -906,7 +928,7 @@ __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list,
 // launch (SYNC_WG threads; s = SYNC_WG int4 of LDS); also the call's bookkeeping: blocks found, passes
 // used, K0's look-back words cleared for the next call.
 template <int S>
-__device__ void wsum_scan(int4* wsum, EntropyMeta* meta, uint32_t* status, int pass, bool rippling, unsigned long long* part,
+__device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_t* status, int pass, bool rippling, unsigned long long* part,
                           uint32_t nparts, int4* s, int4* carry)
 {
     KPEG_GEOMETRY(S);
@@ -939,7 +961,31 @@ __device__ void wsum_scan(int4* wsum, EntropyMeta* meta, uint32_t* status, int p
         if (t == SYNC_WG - 1) *carry = add4(c, incl);
         __syncthreads();
     }
+    // the same for the record counts (one component: the int4 slots' first lanes)
+    uint32_t* sr = reinterpret_cast<uint32_t*>(s);
+    uint32_t* rc = reinterpret_cast<uint32_t*>(carry) + 1;   // (carry->x is read below: a word beside it)
+    if (t == 0) *rc = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nw; base += SYNC_WG) {
+        const uint32_t i = base + t;
+        const uint32_t v = i < nw ? __hip_atomic_load(&wrec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        sr[t] = v;
+        __syncthreads();
+        for (int o = 1; o < SYNC_WG; o <<= 1) {
+            uint32_t x = 0;
+            if ((int)t >= o) x = sr[t - o];
+            __syncthreads();
+            sr[t] += x;
+            __syncthreads();
+        }
+        const uint32_t incl = sr[t], c = *rc;
+        if (i < nw) wrec[i] = c + incl - v;
+        __syncthreads();
+        if (t == SYNC_WG - 1) *rc = c + incl;
+        __syncthreads();
+    }
     if (t == 0) {
+        meta->total_rec = *rc;
         meta->total_blocks = (uint32_t)carry->x;
         uint32_t passes = 1;   // launches of K1 that had work
         for (int q = 1; q < pass; ++q)
@@ -965,9 +1011,11 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     __shared__ uint64_t s_X[ITEMS + 1];
     __shared__ uint32_t s_geo[ITEMS + 1];   // pend | first-of-its-segment << 31
     __shared__ int4 s_cnt[SYNC_WG];
+    __shared__ uint32_t s_nrec[SYNC_WG];
     __shared__ uint16_t s_list[2][ITEMS];
     __shared__ uint32_t s_n[3];
     __shared__ int4 s_red[SYNC_WG / 64];
+    __shared__ uint32_t s_redn[SYNC_WG / 64];
     constexpr uint32_t STAGE_CAP = ITEMS * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
     const int p = a.pass;
@@ -978,7 +1026,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
     const bool rippling = p >= 2 && a.meta->moved[p - 1] != 0;
     if (a.chained && !rippling) {
-        if (g == 0) wsum_scan<S>(a.wsum, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (g == 0) wsum_scan<S>(a.wsum, a.wrec, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
         return;
     }
     if (a.chained) {
@@ -998,7 +1046,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s_n[0] = atomicAdd(&a.meta->ticket, 1u) == (nsub + OWN - 1) / OWN - 1 ? 1u : 0u;
         }
         __syncthreads();
-        if (s_n[0]) wsum_scan<S>(a.wsum, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (s_n[0]) wsum_scan<S>(a.wsum, a.wrec, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
     };
     const uint64_t* Xb_prev = a.Xb + (size_t)((p & 1) ^ 1) * a.nwg_cap;
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
@@ -1086,7 +1134,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 st_iters += r.iters;
 #endif
                 s_X[j + 1] = r.exit_state;
-                if (j >= wu) s_cnt[j - wu] = r.cnt;
+                if (j >= wu) {
+                    s_cnt[j - wu] = r.cnt;
+                    s_nrec[j - wu] = r.nrec;
+                }
                 want = geo.li != 0 && j > 0;
             }
             push_item(want, j, s_list[0], &s_n[0]);
@@ -1097,6 +1148,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
             s_X[j + 1] = a.X[i0 + j];
             s_cnt[j] = a.cnt[i0 + j];
+            s_nrec[j] = a.nrec[i0 + j];
         }
         if (t == 0) {
             s_X[0] = entry;
@@ -1113,10 +1165,18 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     // pass 0 clears the coefficient buffer behind the rounds below, which only touch LDS
     if (p == 0) {
         const uint32_t nwg = (nsub + OWN - 1) / OWN;   // the workgroups that get here
-        const uint64_t per = (a.coef_n16 + nwg - 1) / nwg;
-        const uint64_t b0 = (uint64_t)g * per, b1 = min(a.coef_n16, b0 + per);
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint64_t q = b0 + t; q < b1; q += SYNC_WG) a.coef16[q] = z;
+        if (a.tile_start) {
+            // compact coefficient stream: nothing to clear but the tiles' first-record table (a tile whose first block a
+            // corrupt stream never starts then reads as empty)
+            const uint32_t tper = (a.ntiles + 1 + nwg - 1) / nwg;
+            const uint32_t t0 = min(a.ntiles + 1, g * tper), t1 = min(a.ntiles + 1, t0 + tper);
+            for (uint32_t q = t0 + t; q < t1; q += SYNC_WG) a.tile_start[q] = 0u;
+        } else {
+            const uint64_t per = (a.coef_n16 + nwg - 1) / nwg;
+            const uint64_t b0 = (uint64_t)g * per, b1 = min(a.coef_n16, b0 + per);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint64_t q = b0 + t; q < b1; q += SYNC_WG) a.coef16[q] = z;
+        }
         const uint32_t eper = (a.nblocks + nwg - 1) / nwg;
         const uint32_t e0 = min(a.nblocks, g * eper), e1 = min(a.nblocks, e0 + eper);
         for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = 0x7F800000u;
@@ -1154,7 +1214,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 #endif
                 const bool changed = r.exit_state != before;
                 s_X[j + 1] = r.exit_state;
-                if (j >= wu) s_cnt[j - wu] = r.cnt;
+                if (j >= wu) {
+                    s_cnt[j - wu] = r.cnt;
+                    s_nrec[j - wu] = r.nrec;
+                }
                 want = changed && j + 1 < nit && !(s_geo[j + 1] >> 31);
             }
             push_item(want, j + 1, ln, cn);
@@ -1177,10 +1240,13 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 #endif
 
     int4 tot = make_int4(0, 0, 0, 0);
+    uint32_t trec = 0;
     if (t < nown) {
         a.X[i0 + t] = s_X[wu + t + 1];
         tot = s_cnt[t];
         a.cnt[i0 + t] = tot;
+        trec = s_nrec[t];
+        a.nrec[i0 + t] = trec;
     }
     // per-workgroup totals for the scan
     for (int o = 32; o > 0; o >>= 1) {
@@ -1188,13 +1254,22 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         tot.y += __shfl_down(tot.y, o);
         tot.z += __shfl_down(tot.z, o);
         tot.w += __shfl_down(tot.w, o);
+        trec += __shfl_down(trec, o);
     }
-    if ((t & 63) == 0) s_red[t >> 6] = tot;
+    if ((t & 63) == 0) {
+        s_red[t >> 6] = tot;
+        s_redn[t >> 6] = trec;
+    }
     __syncthreads();
     if (t == 0) {
         int4 w = s_red[0];
-        for (int q = 1; q < SYNC_WG / 64; ++q) w = add4(w, s_red[q]);
+        uint32_t wr = s_redn[0];
+        for (int q = 1; q < SYNC_WG / 64; ++q) {
+            w = add4(w, s_red[q]);
+            wr += s_redn[q];
+        }
         a.wsum[g] = w;
+        a.wrec[g] = wr;
         const uint64_t last = s_X[nit];
         const bool known = (s_geo[wu] >> 31) != 0;   // first own sub-sequence opens a restart segment
         a.assumed[g] = known ? X_NONE : s_X[wu];
@@ -1236,7 +1311,18 @@ struct WriteArgs {
     uint32_t interval;   // 0 = none
     unsigned long long* bslot;  // [nwg_cap] exchange slots, slot g: the block split between workgroups g and g + 1
     uint32_t* status;
+    // compact coefficient stream (k_write<S, true>) instead of the dense layout: one 32-bit record per non-zero AC
+    // coefficient in stream order -- [31:16] value, [13:8] natural position, [4:0] block within its K4 tile (24 blocks =
+    // 8 MCUs) -- every block's DC in a dense int16 array, and the first record of every tile
+    const uint32_t* nrec;    // [nsub_cap] K1's record count per sub-sequence
+    const uint32_t* wrec;    // [nwg_cap] exclusive prefix of the per-workgroup totals
+    uint32_t* rec;
+    uint32_t rec_cap;
+    int16_t* dc16;           // [blocks]
+    uint32_t* tile_start;    // [ntiles + 1], preset to 0 by K1
+    uint32_t ntiles;
 };
+constexpr uint32_t TILE_BLOCKS = 24;   // K4's tile: 8 MCUs x 3 components
 
 // One lane per sub-sequence, one symbol per iteration (a flat state machine: the lanes of a
 // wavefront sit at different points of different blocks).  A lane handles exactly the symbols of
@@ -1251,12 +1337,13 @@ struct WriteArgs {
 // A block split over two workgroups: both sides swap their sum into an exchange slot, and the side that
 // finds the other's sum there settles the bound.  Bounds are preset to +inf (K4's exact path), so a
 // block nobody settles (corrupt stream) is still decoded correctly.
-template <int S>
+template <int S, bool COMPACT>
 __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
 {
     KPEG_GEOMETRY(S);
     __shared__ __attribute__((aligned(16))) LdsTables T;
     __shared__ int4 s_pre[SYNC_WG];   // first the scan of cnt, then every lane's share of the block open at its exit
+    __shared__ uint32_t s_prer[COMPACT ? SYNC_WG : 1];   // scan of the record counts
     __shared__ int4 s_wred[SYNC_WG / 64];
     constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
@@ -1276,18 +1363,26 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup ...
     {
         int4 v = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
+        const uint32_t vr = COMPACT && valid ? a.nrec[i] : 0u;
         s_pre[threadIdx.x] = v;
+        if (COMPACT) s_prer[threadIdx.x] = vr;
         __syncthreads();
         for (int o = 1; o < SYNC_WG; o <<= 1) {
             int4 t = make_int4(0, 0, 0, 0);
-            if ((int)threadIdx.x >= o) t = s_pre[threadIdx.x - o];
+            uint32_t tr = 0;
+            if ((int)threadIdx.x >= o) {
+                t = s_pre[threadIdx.x - o];
+                if (COMPACT) tr = s_prer[threadIdx.x - o];
+            }
             __syncthreads();
             s_pre[threadIdx.x] = add4(s_pre[threadIdx.x], t);
+            if (COMPACT) s_prer[threadIdx.x] += tr;
             __syncthreads();
         }
         const int4 incl = s_pre[threadIdx.x];
         __syncthreads();
         s_pre[threadIdx.x] = make_int4(incl.x - v.x, incl.y - v.y, incl.z - v.z, incl.w - v.w);
+        if (COMPACT) s_prer[threadIdx.x] -= vr;   // exclusive
     }
     // ... + the workgroup's offset, counted from the start of the restart segment.  A segment that began in
     // this workgroup re-bases on a neighbour's scan value; the one open at the workgroup's first
@@ -1373,6 +1468,18 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         uint32_t F = s.q ? F_KEEP : 0u;
         uint32_t ebits = 0;                  // E_BAD / E_DCRUN of every entry met
         uint32_t dcrange = 0;
+        // compact stream: where this lane's records go (K1 counted them: the scan gives every lane its first ordinal), and
+        // which block of which K4 tile the next block to start is (global block gbase + b = 24 tile + bmn)
+        uint32_t ord = 0, ord_end = 0, bmn = 0, tn = 0, bm_cur = 0;
+        bool last_block_ended_here = false;
+        if (COMPACT) {
+            ord = a.wrec[blockIdx.x] + s_prer[threadIdx.x];
+            ord_end = min(ord + a.nrec[i], a.rec_cap);
+            const uint32_t gbn = seg_mcu0 * 3 + b;
+            tn = gbn / TILE_BLOCKS;
+            bmn = gbn - tn * TILE_BLOCKS;
+            bm_cur = bmn ? bmn - 1 : TILE_BLOCKS - 1;   // the block in progress at entry (if any)
+        }
         float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
         int nnz = 0;
         const uint32_t gbase = seg_mcu0 * 3;
@@ -1409,6 +1516,15 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                 pd2 = n;
                 gb = gbase + b;
                 b++;
+                if (COMPACT) {
+                    bm_cur = bmn;
+                    if (bmn == 0 && tn <= a.ntiles) a.tile_start[tn] = ord;   // this tile's records begin here
+                    bmn++;
+                    if (bmn == TILE_BLOCKS) {
+                        bmn = 0;
+                        tn++;
+                    }
+                }
                 F = (F & (F_OVER | F_HEAD | F_HEAD_NONCORNER)) | F_STARTED | F_INSIDE | ((e >> 25) & 1u);   // E_KEEP -> F_KEEP; b < blk_limit here
             }
             const int v = isdc ? n : ext;
@@ -1417,7 +1533,16 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             if (!isdc && !(e & E_ZERO) && kraw > 64) F |= F_OVER;
             if ((F & F_INSIDE) && (isdc || ((F & F_KEEP) && posraw < 64))) {
 #if KPEG_ABLATE_W != 1 && KPEG_ABLATE_W != 3
-                a.coef[((size_t)gb << 6) | T.zz[pos]] = (int16_t)v;
+                if (COMPACT) {
+                    if (isdc) {
+                        a.dc16[gb] = (int16_t)v;
+                    } else if (v != 0 && ord < ord_end) {   // (ord < ord_end always holds: K1 counted by the same rule)
+                        a.rec[ord] = ((uint32_t)v << 16) | ((uint32_t)T.zz[pos] << 8) | bm_cur;
+                        ord++;
+                    }
+                } else {
+                    a.coef[((size_t)gb << 6) | T.zz[pos]] = (int16_t)v;
+                }
 #endif
                 // == the terms of block_ebound()'s A in idct_colour.hip.h (DC: 0.25 cc00 Q00, any rounding order is inside U's slack)
                 Asum += fabsf((float)v * T.mscale_zz[tdc][pos]);
@@ -1428,6 +1553,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             }
             if (adv && !isdc) {
                 // the block is complete
+                if (COMPACT && b == blk_limit && (F & F_INSIDE)) last_block_ended_here = true;
                 if (!(F & F_INSIDE)) {
                     // a block the segment does not have (corrupt stream): no bound to write
                 } else if (F & F_STARTED) {
@@ -1465,6 +1591,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         tail_chroma = tb >= 2 * LUT_BYTES ? 1 : 0;
         if (k != 0 && (F & F_INSIDE))
             share = make_int4(__float_as_int(Asum), nnz, SH_OPEN | ((F & F_NONCORNER) ? 0 : SH_CORNER) | ((F & F_STARTED) ? SH_STARTED : 0), 0);
+        // end of the last tile: by the lane in which the stream's last block ended (bits after it are ignored, as the
+        // reference ignores them: a later lane never gets here)
+        if (COMPACT && last_block_ended_here && g.seg + 1 == nseg) a.tile_start[a.ntiles] = ord;
         // the last sub-sequence of a segment must have produced the segment's last block, all of it
         if (g.li + 1 == a.sub_base[g.seg + 1] - first) {
             if (b < blk_limit) err |= 128;
@@ -1582,6 +1711,7 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     if ((rc = ent_grow(&S->d_state, &S->state_cap, ((size_t)nsub_cap + 5 * (size_t)nwg_cap) * 8 + 64, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_cnt, &S->cnt_cap, (size_t)nsub_cap * 16, L.stream, err))) return rc;
     if ((rc = ent_grow(&S->d_wsum, &S->wsum_cap, ((size_t)nwg_cap + 2) * 16, L.stream, err))) return rc;
+    if ((rc = ent_grow(&S->d_nrec, &S->nrec_cap, ((size_t)nsub_cap + (size_t)nwg_cap + 2) * 4, L.stream, err))) return rc;
     if (!S->d_meta) {
         ENT_HIP(hipMalloc((void**)&S->d_meta, sizeof(EntropyMeta)));
         ENT_HIP(hipMemset(S->d_meta, 0, sizeof(EntropyMeta)));   // K0's tickets start at zero and are left at zero
@@ -1629,6 +1759,10 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.assumed = assumed;
     sa.cnt = cnt;
     sa.wsum = (int4*)S->d_wsum;
+    sa.nrec = (uint32_t*)S->d_nrec;
+    sa.wrec = sa.nrec + nsub_cap;
+    sa.tile_start = L.d_tile_start;
+    sa.ntiles = L.ntiles;
     sa.coef16 = (uint4*)L.d_coef;
     sa.coef_n16 = (uint64_t)L.nmcu * 24;   // 384 bytes per MCU
     sa.ebound = (uint32_t*)L.d_ebound;
@@ -1668,7 +1802,15 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     wa.interval = L.restart_interval;
     wa.bslot = bslot;
     wa.status = L.d_status;
-    hipLaunchKernelGGL(k_write<SB>, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
+    wa.nrec = sa.nrec;
+    wa.wrec = sa.wrec;
+    wa.rec = L.d_rec;
+    wa.rec_cap = L.rec_cap;
+    wa.dc16 = L.d_dc16;
+    wa.tile_start = L.d_tile_start;
+    wa.ntiles = L.ntiles;
+    if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
+    else hipLaunchKernelGGL((k_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);
     mark(5);
     ENT_HIP(hipGetLastError());

@@ -83,6 +83,12 @@ struct IdctParams {
     uint8_t* const* rgb_table;  // fused batch: output base of every image (device array), else null and rgb is the base
     uint32_t rows_per_img;      // ... MCU rows per image
     uint32_t keep_status; // batch lanes: leave the device words standing (error flags and counters accumulate over the lane's images)
+    // k_idct_colour_fast<true>: the compact coefficient stream K2 writes (entropy.hip.h, WriteArgs) instead of `coef`.
+    // A tile is 8 consecutive MCUs of the stream (mcus_w is a multiple of 8 on this path), its records are contiguous.
+    const uint32_t* rec;          // [31:16] value, [13:8] natural position, [4:0] block within the tile (0..23)
+    const int16_t* dc16;          // [blocks] absolute DC of every block
+    const uint32_t* tile_start;   // [ntiles + 1] first record of every tile
+    uint32_t rec_cap;             // records the buffer holds (bounds what a corrupt table can make a wavefront read)
 };
 
 constexpr uint32_t KPEG_STATUS_WORDS = 16 + 256 + 64;   // [1] error flags, [2] K1 passes, [3] + [272..335] end-of-call tickets, [16..271] counters
@@ -578,6 +584,9 @@ __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, 
 constexpr int QUEUE_FLUSH = KPEG_QUEUE_FLUSH;   // queued pixels that make a fix-up pass worth its fixed cost
 constexpr int OVER_CAP = TILE_MCUS * 64 - (QUEUE_CAP - QUEUE_FLUSH);   // a tile starts with at least QUEUE_CAP - QUEUE_FLUSH free entries
 constexpr int QUEUE_WORDS = 8;    // per queued pixel: position, 3 rounded samples, 3 keys (>= 0: that component is unsafe), pad
+constexpr int QUEUE_WORDS_COMPACT = 16;   // ... + words 8..13: the 2x2 corner coefficients of the pixel's three blocks (the compact
+                                          // stream has no block to read them from later)
+constexpr int IMG_BYTES = 24 * 128;       // compact path: the tile's 24 blocks rebuilt in LDS, natural order, int16
 
 #ifdef KPEG_K4_STAMP
 __device__ unsigned long long g_k4_stamp[8192 * 4];
@@ -594,10 +603,13 @@ __device__ unsigned long long g_k4_stamp[8192 * 4];
 // per (pixel, component), and patches the three bytes in global memory.  Handling them where they are found -- a few
 // lanes of a wavefront, several times per tile -- cost 37 % of the kernel's time (profiles/r01_g: 0.103 -> 0.065 ms with
 // the handling compiled out).
+template <bool COMPACT>
 __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, QTables qt)
 {
+    constexpr int QW = QUEUE_WORDS_COMPACT;   // both layouts stash the blocks' corner words in the queue entry
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_all[K4_WAVES][8 * TILE_ROW_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_queue_all[K4_WAVES][QUEUE_CAP * QUEUE_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_queue_all[K4_WAVES][QUEUE_CAP * QW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_img_all[COMPACT ? K4_WAVES : 1][IMG_BYTES / 4];
     __shared__ uint16_t s_over_all[K4_WAVES][OVER_CAP];   // unsafe pixels a tile has beyond the queue's room: bits [11:0] of the position word (the
                                             // fix-up pass that takes them runs before the next tile: the tile is known)
     __shared__ __attribute__((aligned(16))) float s_m[2][64];     // AC input scales, natural order
@@ -614,6 +626,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint8_t* const s_tile = s_tile_all[wave];
     uint32_t* const s_queue = s_queue_all[wave];
+    uint32_t* const s_img = s_img_all[COMPACT ? wave : 0];
     uint16_t* const s_over = s_over_all[wave];
     const int lane8 = tid & 7;          // lane within the MCU group = output pixel row
     const int grp = tid >> 3;           // MCU within the tile, 0..7
@@ -738,8 +751,8 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, f0 = -1.0f, f1 = -1.0f, f2 = -1.0f;
             if (valid) {
                 if (e < nq) {
-                    const uint4v a = *reinterpret_cast<const uint4v*>(s_queue + e * QUEUE_WORDS);
-                    const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QUEUE_WORDS + 4);
+                    const uint4v a = *reinterpret_cast<const uint4v*>(s_queue + e * QW);
+                    const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 4);
                     pos = a.x;
                     r0 = __uint_as_float(a.y), r1 = __uint_as_float(a.z), r2 = __uint_as_float(a.w);
                     f0 = __uint_as_float(b.x), f1 = __uint_as_float(b.y), f2 = __uint_as_float(b.z);
@@ -758,13 +771,24 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
 #ifdef KPEG_FX_SKIP_CORNER
             const bool cn0 = false, cn1 = false, cn2 = false;
 #else
-            const bool cn0 = need0 && (pos & (1u << 9)), cn1 = need1 && (pos & (1u << 10)), cn2 = need2 && (pos & (1u << 11));
+            // A queue entry carries the corner words of its three blocks (stashed when it was pushed: no load, no memory latency
+            // in this pass); an overflow-list pixel has none: dense layout -> two 4-byte loads per block, compact stream -> the
+            // general way (from the tile's image).
+            const bool from_queue = valid && e < nq;
+            const bool stashed = !COMPACT || from_queue;
+            const bool cn0 = need0 && (pos & (1u << 9)) && stashed, cn1 = need1 && (pos & (1u << 10)) && stashed, cn2 = need2 && (pos & (1u << 11)) && stashed;
 #endif
-            const uint32_t* c32 = reinterpret_cast<const uint32_t*>(p.coef) + (size_t)mcu * 96;
             uint32_t w00 = 0, w01 = 0, w10 = 0, w11 = 0, w20 = 0, w21 = 0;
-            if (cn0) w00 = c32[0], w01 = c32[4];
-            if (cn1) w10 = c32[32], w11 = c32[36];
-            if (cn2) w20 = c32[64], w21 = c32[68];
+            if (from_queue) {
+                const uint4v cw = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 8);
+                const uint2 cw2 = *reinterpret_cast<const uint2*>(s_queue + e * QW + 12);
+                w00 = cw.x, w01 = cw.y, w10 = cw.z, w11 = cw.w, w20 = cw2.x, w21 = cw2.y;
+            } else if constexpr (!COMPACT) {
+                const uint32_t* c32 = reinterpret_cast<const uint32_t*>(p.coef) + (size_t)mcu * 96;
+                if (cn0) w00 = c32[0], w01 = c32[4];
+                if (cn1) w10 = c32[32], w11 = c32[36];
+                if (cn2) w20 = c32[64], w21 = c32[68];
+            }
             // the others: wave-uniform lists of (lane, component)
             unsigned long long g0 = __ballot(need0 && !cn0), g1 = __ballot(need1 && !cn1), g2 = __ballot(need2 && !cn2);
 #ifdef KPEG_FX_SKIP_COOP
@@ -776,7 +800,18 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                 L = (uint32_t)__builtin_ctzll(mm);
                 mm &= mm - 1;
             };
-            const int16_t* c16 = p.coef;
+            // The coefficient at position `lane` of block c of MCU mcuL (wave-uniform arguments), for the samples the whole
+            // wavefront evaluates.  Dense layout: one coalesced 128-byte load.  Compact stream: from the tile's image in LDS --
+            // only pixels of the tile that was computed last get here (the overflow list, settled before the next tile;
+            // queued pixels had their non-corner samples settled by resolve_noncorner while their tile's image stood).
+            auto fetch_coef = [&](uint32_t mcuL, uint32_t c, int) -> int {
+                if constexpr (!COMPACT) {
+                    return p.coef[((size_t)mcuL * 3 + c) * 64 + lane];
+                } else {
+                    const uint16_t* img16 = reinterpret_cast<const uint16_t*>(s_img);
+                    return (int)(int16_t)img16[((mcuL & (TILE_MCUS - 1)) * 3 + c) * 64 + lane];
+                }
+            };
 #ifndef KPEG_COOP_BATCH
 #define KPEG_COOP_BATCH 2
 #endif
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                         uint32_t c, L;
                         pop(a0, a1, a2, c, L);
                         const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
-                        cf[k] = c16[((size_t)mcuL * 3 + c) * 64 + lane];
+                        cf[k] = fetch_coef(mcuL, c, k);
                     }
                 }
             }
@@ -818,7 +853,11 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                     const bool nd = c == 0 ? (need0 && !cn0) : (c == 1 ? (need1 && !cn1) : (need2 && !cn2));
                     if (__ballot(nd) == 0) continue;
                     int S = 128;
-                    if (nd) S = exact_sample_lane(reinterpret_cast<const uint4*>(p.coef) + ((size_t)mcu * 3 + c) * 8, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
+                    if (nd) {
+                        const uint4* blk = COMPACT ? reinterpret_cast<const uint4*>(s_img) + ((mcu & (TILE_MCUS - 1)) * 3 + c) * 8
+                                                   : reinterpret_cast<const uint4*>(p.coef) + ((size_t)mcu * 3 + c) * 8;
+                        S = exact_sample_lane(blk, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
+                    }
                     const float rv = (float)(S - 128);
                     if (nd) {
                         if (c == 0) r0 = rv;
@@ -854,7 +893,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                             uint32_t c, L;
                             pop(a0, a1, a2, c, L);
                             const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
-                            cf[k] = c16[((size_t)mcuL * 3 + c) * 64 + lane];
+                            cf[k] = fetch_coef(mcuL, c, k);
                         }
                     }
                 }
@@ -879,6 +918,68 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         }
     };
 
+    // Compact stream only.  The queue entries [first, last) were pushed by the tile whose image stands in LDS; those of
+    // them with an unsafe sample in a block that is NOT corner-only get that sample evaluated now, in the reference's order,
+    // from the image (the whole wavefront per sample, lane = coefficient position; lane-parallel when there are many) and
+    // written back into the entry with its key cleared: later the compact stream offers no block to read.  What remains
+    // for the deferred pass: corner-only samples (from the stashed words), the colour conversion and the three bytes.
+    auto resolve_noncorner = [&](uint32_t first, uint32_t last) {
+        uint32_t lane = (uint32_t)tid;
+        asm volatile("" : "+v"(lane));
+        const uint32_t e = first + lane;
+        const bool valid = e < last;
+        uint32_t pos = 0;
+        float f0 = -1.0f, f1 = -1.0f, f2 = -1.0f;
+        if (valid) {
+            pos = s_queue[e * QW];
+            const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 4);
+            f0 = __uint_as_float(b.x), f1 = __uint_as_float(b.y), f2 = __uint_as_float(b.z);
+        }
+        const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
+        const bool n0 = f0 >= 0.0f && !(pos & (1u << 9)), n1 = f1 >= 0.0f && !(pos & (1u << 10)), n2 = f2 >= 0.0f && !(pos & (1u << 11));
+        unsigned long long g0 = __ballot(n0), g1 = __ballot(n1), g2 = __ballot(n2);
+        if (!(g0 | g1 | g2)) return;
+        float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        const uint16_t* img16 = reinterpret_cast<const uint16_t*>(s_img);
+        if (__popcll(g0) + __popcll(g1) + __popcll(g2) > 6) {
+            // a cluster: every lane its own samples, component by component
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                const bool nd = c == 0 ? n0 : (c == 1 ? n1 : n2);
+                if (__ballot(nd) == 0) continue;
+                int S = 128;
+                if (nd) S = exact_sample_lane(reinterpret_cast<const uint4*>(s_img) + (g * 3 + c) * 8, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
+                const float rv = (float)(S - 128);
+                if (c == 0) r0 = rv;
+                else if (c == 1) r1 = rv;
+                else r2 = rv;
+            }
+        } else {
+            const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
+            while (g0 | g1 | g2) {   // wave-uniform
+                unsigned long long& mm = g0 ? g0 : (g1 ? g1 : g2);
+                const uint32_t c = g0 ? 0u : (g1 ? 1u : 2u);
+                const uint32_t L = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                const uint32_t gL = (uint32_t)__builtin_amdgcn_readlane((int)g, (int)L);
+                const int xL = __builtin_amdgcn_readlane((int)x, (int)L), yL = __builtin_amdgcn_readlane((int)y, (int)L);
+                const int F = (int)(int16_t)img16[(gL * 3 + c) * 64 + lane] * (int)s_qi[c ? 1 : 0][lane];   // m_8x8block after MCU.cpp:110-112
+                const int S = exact_sample_wave(ccl * (float)F, s_cos, xL, yL, F != 0);
+                const float rv = (float)(S - 128);
+                if (lane == L) {
+                    if (c == 0) r0 = rv;
+                    else if (c == 1) r1 = rv;
+                    else r2 = rv;
+                }
+            }
+        }
+        if (n0) s_queue[e * QW + 1] = __float_as_uint(r0), s_queue[e * QW + 4] = __float_as_uint(-1.0f);   // key < 0: settled
+        if (n1) s_queue[e * QW + 2] = __float_as_uint(r1), s_queue[e * QW + 5] = __float_as_uint(-1.0f);
+        if (n2) s_queue[e * QW + 3] = __float_as_uint(r2), s_queue[e * QW + 6] = __float_as_uint(-1.0f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
     bool have_prev = false;
     size_t prev_off = 0;
     uint32_t prev_nm = 0;
@@ -889,11 +990,22 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
     // for one tile ahead (a second register set: the 16-wavefront workgroup leaves 128 VGPRs per lane), so that a
     // wavefront's tile costs it its instructions and not a memory round trip on top -- with four wavefronts per SIMD the
     // others cannot cover that wait.
+    // Compact stream: the tile's records (4 bytes per non-zero AC coefficient, ~90 per tile on the 8K workload against 3 KiB of
+    // dense rows), its 24 DC values and the bounds are asked for one tile ahead, the two words of the first-record table
+    // two tiles ahead (they say where the records are); the blocks are rebuilt in LDS when the tile's turn comes.
     struct TileIn {
-        uint4 d0, d1, d2;
+        uint4 d0, d1, d2;        // dense layout: this lane's coefficient rows
         float e0, e1, e2;
+        uint32_t r0, r1, dcw;    // compact stream: records rs + lane, rs + 64 + lane; DC of block `lane` of the tile
+        uint32_t rs, rn;         // ... first record and record count (wave-uniform)
     };
-    auto issue_loads = [&](uint32_t tk, TileIn& in) {
+    auto tile_records = [&](uint32_t tk, uint32_t& rs, uint32_t& rn) {
+        const uint32_t tile = wg_tile0 + tk;
+        const uint32_t a = p.tile_start[tile], b = p.tile_start[tile + 1];   // wave-uniform addresses: scalar loads
+        rs = a;
+        rn = (b >= a && b <= p.rec_cap && b - a <= 24u * 63u) ? b - a : 0u;   // (a corrupt stream may leave anything in the table)
+    };
+    auto issue_loads = [&](uint32_t tk, TileIn& in, uint32_t rs, uint32_t rn) {
         const uint32_t tile = wg_tile0 + tk;
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
@@ -908,14 +1020,31 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
 #else
         const size_t mcu_ld = (size_t)trow * p.mcus_w + m0;
 #endif
-        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu_ld * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
-        in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+        if constexpr (COMPACT) {
+            in.rs = rs, in.rn = rn;
+            const uint32_t* rp = p.rec + rs;
+            uint32_t l = (uint32_t)tid;
+            asm volatile("" : "+v"(l));
+            in.r0 = l < rn ? rp[l] : 31u;            // (block 31 does not exist: skipped)
+            in.r1 = l + 64u < rn ? rp[l + 64u] : 31u;
+            in.dcw = l < 24u ? (uint32_t)(uint16_t)p.dc16[mcu_ld * 3 + l] : 0u;
+        } else {
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu_ld * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
+            in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+        }
         const float* eb = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(p.ebound + mcu_ld * 3) + lane_mcu * 12u);
         in.e0 = eb[0], in.e1 = eb[1], in.e2 = eb[2];
     };
     uint32_t tilek_cur = take_tile(), tilek_next = take_tile();
     TileIn cur, nxt;
-    if (tilek_cur < wg_ntiles) issue_loads(tilek_cur, cur);
+    uint32_t rs_next = 0, rn_next = 0, rs_after = 0, rn_after = 0;
+    if (tilek_cur < wg_ntiles) {
+        uint32_t rs = 0, rn = 0;
+        if constexpr (COMPACT) tile_records(tilek_cur, rs, rn);
+        issue_loads(tilek_cur, cur, rs, rn);
+    }
+    if constexpr (COMPACT)
+        if (tilek_next < wg_ntiles) tile_records(tilek_next, rs_next, rn_next);
     for (;;) {
         const uint32_t tilek = tilek_cur;              // this tile's number inside the workgroup's range
         const bool more = tilek < wg_ntiles;           // wave-uniform
@@ -923,14 +1052,47 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         uint32_t tilek_after = 0;
         if (more) {
         tilek_after = take_tile();
-        if (tilek_next < wg_ntiles) issue_loads(tilek_next, nxt);   // the next tile's inputs travel while this one is computed
+        if constexpr (COMPACT)
+            if (tilek_after < wg_ntiles) tile_records(tilek_after, rs_after, rn_after);   // two tiles ahead: nothing waits for these
+        if (tilek_next < wg_ntiles) issue_loads(tilek_next, nxt, rs_next, rn_next);   // the next tile's inputs travel while this one is computed
         asm volatile("" ::: "memory");
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
         const bool active = (uint32_t)grp < nm;
-        const uint4 d0 = cur.d0, d1 = cur.d1, d2 = cur.d2;
+        uint4 d0, d1, d2;
+        if constexpr (COMPACT) {
+            // rebuild the tile's 24 blocks in LDS (zero, scatter the records, the DC values), then read this lane's rows
+            uint4v* img4 = reinterpret_cast<uint4v*>(s_img);
+            const uint4v z = {0u, 0u, 0u, 0u};
+            img4[tid] = z, img4[tid + 64] = z, img4[tid + 128] = z;
+            uint16_t* img16 = reinterpret_cast<uint16_t*>(s_img);
+            auto put = [&](uint32_t r) {
+                const uint32_t bm = r & 31u;
+                if (bm < 24u) img16[bm * 64u + ((r >> 8) & 63u)] = (uint16_t)(r >> 16);
+            };
+            put(cur.r0);
+            put(cur.r1);
+            for (uint32_t b0 = 128; b0 < cur.rn; b0 += 64) {   // (dense tiles only)
+                const uint32_t idx = b0 + (uint32_t)tid;
+                if (idx < cur.rn) put(p.rec[cur.rs + idx]);
+            }
+            if (tid < 24) img16[tid * 64] = (uint16_t)cur.dcw;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4* rows = reinterpret_cast<const uint4*>(s_img) + (grp * 3) * 8 + u;
+            d0 = rows[0], d1 = rows[8], d2 = rows[16];
+        } else {
+            d0 = cur.d0, d1 = cur.d1, d2 = cur.d2;
+        }
         const float e0 = cur.e0, e1 = cur.e1, e2 = cur.e2;
+        // The first word of rows 0 and 1 of the MCU's three blocks (coefficients (0,0),(0,1) and (1,0),(1,1)): they sit on
+        // lanes 0 and 4 of the group.  A queued pixel takes them along, so the fix-up pass settles corner-only blocks (nine
+        // unsafe samples in ten) without touching memory.
+        const int lrow0 = tid & 56, lrow1 = lrow0 | 4;
+        const uint32_t cw00 = (uint32_t)__shfl((int)d0.x, lrow0), cw01 = (uint32_t)__shfl((int)d0.x, lrow1);
+        const uint32_t cw10 = (uint32_t)__shfl((int)d1.x, lrow0), cw11 = (uint32_t)__shfl((int)d1.x, lrow1);
+        const uint32_t cw20 = (uint32_t)__shfl((int)d2.x, lrow0), cw21 = (uint32_t)__shfl((int)d2.x, lrow1);
         const size_t cur_off = tile_offset(trow, m0);
         if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
         have_prev = true;
@@ -994,6 +1156,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         const uint32_t pos_lane = (uint32_t)grp | ((uint32_t)lane8 << 3) | (tilek << 12) | ((__float_as_uint(e0) >> 31) << 9) |
                                   ((__float_as_uint(e1) >> 31) << 10) | ((__float_as_uint(e2) >> 31) << 11);
         const unsigned long long active_mask = __ballot(active);
+        bool pushed_nc = false;   // compact stream: this tile queued a pixel with an unsafe sample in a block that is not corner-only
         // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
         auto pixel_loop = [&](auto with_wide) {
 #pragma unroll
@@ -1054,7 +1217,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                     if ((int)safe >= 0 && active) {
                         const uint32_t pw = pos_lane | ((uint32_t)i << 6);
                         if (slot < QUEUE_CAP) {
-                            uint32_t* q = s_queue + slot * QUEUE_WORDS;
+                            uint32_t* q = s_queue + slot * QW;
                             q[0] = pw;
 #ifndef KPEG_PUSH_POS_ONLY
                             q[1] = __float_as_uint(ry), q[2] = __float_as_uint(rb), q[3] = __float_as_uint(rr);
@@ -1065,11 +1228,21 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                             q[4] = __float_as_uint(fy), q[5] = __float_as_uint(fb), q[6] = __float_as_uint(fr);
 #endif
 #endif
+                            // the 2x2 corner of the pixel's three blocks (rows 0 and 1, columns 0 and 1)
+                            q[8] = cw00, q[9] = cw01, q[10] = cw10, q[11] = cw11, q[12] = cw20, q[13] = cw21;
                         } else {
                             s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
                         }
                     }
                     nq += __popcll(bal);
+                    if constexpr (COMPACT) {
+#if KPEG_K4_MAX3
+                        const float fy = fabsf(dy) + nthr0, fb = fabsf(db) + nthr1, fr = fabsf(dr) + nthr2;
+#endif
+                        const uint32_t ncb = (~__float_as_uint(fy) & ~__float_as_uint(e0)) | (~__float_as_uint(fb) & ~__float_as_uint(e1)) |
+                                             (~__float_as_uint(fr) & ~__float_as_uint(e2));   // sign set: unsafe (key >= 0) in a block whose bound is positive (not corner-only)
+                        pushed_nc = pushed_nc || __ballot((int)ncb < 0 && (int)safe >= 0 && active) != 0;
+                    }
                 }
 #else
                 (void)safe;
@@ -1091,6 +1264,11 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             nover = nq - QUEUE_CAP;
             nq = QUEUE_CAP;
         }
+        if constexpr (COMPACT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (pushed_nc) resolve_noncorner(min(nq_tile, (uint32_t)QUEUE_CAP), nq);   // while this tile's image stands
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the next iteration writes this tile back before its own colour phase overwrites the LDS tile
@@ -1109,6 +1287,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         cur = nxt;
         tilek_cur = tilek_next;
         tilek_next = tilek_after;
+        rs_next = rs_after, rn_next = rn_after;
     }
     if (have_prev) write_back(prev_off, prev_nm);
 #if defined(KPEG_COUNT_COOP) || defined(KPEG_COUNT_MANY) || defined(KPEG_COUNT_FLUSH) || defined(KPEG_COUNT_CORNER)

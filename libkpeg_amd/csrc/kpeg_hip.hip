@@ -49,6 +49,14 @@ struct kpeg_hip_ctx {
     size_t rgb_cap = 0;
     void* d_ebound = nullptr;  // per-block error bounds for K4 (written by K2 or k_ebound)
     size_t ebound_cap = 0;
+    // compact coefficient stream between K2 and K4 (sparse streams whose MCU rows are whole K4 tiles): records, DC values, first record of every tile
+    void* d_rec = nullptr;
+    size_t rec_cap = 0;
+    void* d_dc16 = nullptr;
+    size_t dc16_cap = 0;
+    void* d_tstart = nullptr;
+    size_t tstart_cap = 0;
+    int coef_layout = 0;       // test hook: 0 = chosen per call, 1 = always the dense layout, 2 = the compact stream wherever it is possible
     EntropyScratch ent;        // K0..K3 work buffers
     // [0] unused, [1] entropy error flag, [2] sync passes, [16..271] K4 exact-pixel counters
     uint32_t* d_status = nullptr;
@@ -171,11 +179,12 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
         // K4's workgroups are persistent workers, one per CU (K4_WAVES wavefronts each): launch exactly as many as stay
         // resident (more would run as a second, partly filled round).  KPEG_K4_WGS_PER_CU: timing experiments only.
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_idct_colour_fast, K4_THREADS, 0) == hipSuccess && nb > 0) ctx->k4_wgs_per_cu = nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_idct_colour_fast<false>, K4_THREADS, 0) == hipSuccess && nb > 0) ctx->k4_wgs_per_cu = nb;
         if (const char* s = std::getenv("KPEG_K4_WGS_PER_CU")) {
             const int v = std::atoi(s);
             if (v > 0) ctx->k4_wgs_per_cu = v;
         }
+        if (const char* s = std::getenv("KPEG_COEF_LAYOUT")) ctx->coef_layout = std::atoi(s);   // experiments: as kpeg_hip_debug_set key 7
         if (std::getenv("KPEG_DEBUG")) std::fprintf(stderr, "kpeg_hip: K4 workgroups per CU: %d (occupancy query %d), %d wavefronts each\n", ctx->k4_wgs_per_cu, nb, K4_WAVES);
     }
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess)
@@ -213,6 +222,9 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     if (ctx->d_scan) (void)hipFree(ctx->d_scan);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
     if (ctx->d_ebound) (void)hipFree(ctx->d_ebound);
+    if (ctx->d_rec) (void)hipFree(ctx->d_rec);
+    if (ctx->d_dc16) (void)hipFree(ctx->d_dc16);
+    if (ctx->d_tstart) (void)hipFree(ctx->d_tstart);
     entropy_scratch_free(&ctx->ent);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -300,6 +312,8 @@ extern "C" int kpeg_hip_sync(kpeg_hip_ctx* ctx)
                 rc = KPEG_HIP_E_DEVICE;
             } else {
                 ctx->last_error = "entropy decode flagged the stream as invalid (code " + std::to_string(ctx->h_status[1]) + ")";
+                if (ctx->h_status[1] & 1u)
+                    ctx->last_error += ": " + std::to_string(ctx->h_status[4]) + " restart segments found, the frame has " + std::to_string(ctx->h_status[5]);
                 rc = KPEG_HIP_E_STREAM;
             }
             ctx->status_clean = false;   // the next call clears the device words before it starts
@@ -352,9 +366,9 @@ static void natural_qtables(const kpeg_frame* f, QTables* qt)
 
 // K4 launch: rows [0, mcu_rows) of d_coef -> d_rgb.  ctx->d_ebound must hold the blocks' error bounds.
 static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_coef, uint8_t* d_rgb, uint32_t mcu_rows,
-                       uint8_t* const* d_rgb_table = nullptr, uint32_t rows_per_img = 0)
+                       uint8_t* const* d_rgb_table = nullptr, uint32_t rows_per_img = 0, bool compact = false)
 {
-    if ((reinterpret_cast<uintptr_t>(d_coef) & 15) || (reinterpret_cast<uintptr_t>(d_rgb) & 7)) {
+    if ((!compact && (reinterpret_cast<uintptr_t>(d_coef) & 15)) || (reinterpret_cast<uintptr_t>(d_rgb) & 7)) {
         ctx->last_error = "device coefficient buffer must be 16-byte aligned, rgb buffer 8-byte aligned";
         return KPEG_HIP_E_ARG;
     }
@@ -374,6 +388,10 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     p.rgb_table = d_rgb_table;
     p.rows_per_img = rows_per_img;
     p.skip_exact = ctx->idct_mode == 2;
+    p.rec = compact ? (const uint32_t*)ctx->d_rec : nullptr;
+    p.dc16 = compact ? (const int16_t*)ctx->d_dc16 : nullptr;
+    p.tile_start = compact ? (const uint32_t*)ctx->d_tstart : nullptr;
+    p.rec_cap = compact ? (uint32_t)std::min<size_t>(ctx->rec_cap / 4, 0xFFFFFFFFu) : 0u;
     if (ctx->idct_mode == 1) {
         p.tiles_w = 0;
         p.ntiles = 0;
@@ -396,7 +414,8 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
         const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)ctx->k4_wgs_per_cu;
         const uint32_t want = (p.ntiles + K4_WAVES - 1) / K4_WAVES;   // at least a tile per wavefront
         const uint32_t grid = want < resident ? want : resident;
-        hipLaunchKernelGGL(k_idct_colour_fast, dim3(grid), dim3(K4_THREADS), 0, ctx->stream, p, qt);
+        if (compact) hipLaunchKernelGGL(k_idct_colour_fast<true>, dim3(grid), dim3(K4_THREADS), 0, ctx->stream, p, qt);
+        else hipLaunchKernelGGL(k_idct_colour_fast<false>, dim3(grid), dim3(K4_THREADS), 0, ctx->stream, p, qt);
     }
     HIPCHK(ctx, hipGetLastError());
     return KPEG_HIP_OK;
@@ -463,8 +482,24 @@ extern "C" int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
 // ---------------------------------------------------------------------------------------------
 // Entropy decode + IDCT
 
+// The compact coefficient stream between K2 and K4 (entropy.hip.h: WriteArgs) instead of the dense int16 layout: K1 clears
+// nothing, K2 writes 4 bytes per non-zero AC coefficient in stream order instead of scattering 2-byte stores over 384 bytes
+// per MCU, K4 reads a tenth of the bytes.  For sparse streams (the 96-bit sub-sequence path) whose MCU rows are whole K4
+// tiles (width a multiple of 64), and never for the reference-order cross-check kernel, which reads dense blocks.
+static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t scan_bytes, uint64_t nmcu)
+{
+    if (ctx->coef_layout == 1 || ctx->idct_mode == 1) return false;
+    if ((f->width / 8) % TILE_MCUS != 0) return false;
+    const bool dense = ctx->subseq ? ctx->subseq >= SUBSEQ_DENSE : scan_bytes * 8 >= nmcu * 64 * 4;   // entropy_decode_launch's rule
+    if (ctx->coef_layout == 2) return true;
+    // While the dense coefficients (384 bytes per MCU) stay in the 256 MiB Infinity Cache between K2 and K4 the dense layout
+    // costs K4 no HBM reads and no rebuild in LDS: measured equal end to end on the 8K image (190 MiB), and K4 itself 64 against
+    // 73 us.  Beyond that the compact stream wins: 16384x16384 2.05 -> 1.56 ms, 256 x 1080p 141 -> 180 Gpixel/s (profiles/r02).
+    return !dense && nmcu * 384 > ((uint64_t)224 << 20);
+}
+
 static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint32_t nmcu,
-                       int16_t* d_coef, const EntropyLaunch* batch = nullptr)
+                       int16_t* d_coef, const EntropyLaunch* batch = nullptr, bool compact = false)
 {
     EntropyTables tabs;
     int rc = build_entropy_tables(f, &tabs);
@@ -486,6 +521,19 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.sync_passes = ctx->sync_passes;
     L.warm = ctx->warm;
     L.subseq = ctx->subseq;
+    if (compact) {
+        // a record takes at least two bits of the stream (a one-bit code and a one-bit magnitude), a block holds at most 63
+        const uint64_t bytes = batch ? batch->total_len : (uint64_t)scan_len;
+        const uint64_t nrec = std::min<uint64_t>(bytes * 4, (uint64_t)nmcu * 3 * 63) + 64;
+        if ((rc = grow(ctx, &ctx->d_rec, &ctx->rec_cap, nrec * 4))) return rc;
+        if ((rc = grow(ctx, &ctx->d_dc16, &ctx->dc16_cap, (size_t)nmcu * 3 * 2 + 64))) return rc;
+        if ((rc = grow(ctx, &ctx->d_tstart, &ctx->tstart_cap, ((size_t)nmcu / TILE_MCUS + 2) * 4))) return rc;
+        L.d_rec = (uint32_t*)ctx->d_rec;
+        L.rec_cap = (uint32_t)std::min<uint64_t>(nrec, 0xFFFFFFFFu);
+        L.d_dc16 = (int16_t*)ctx->d_dc16;
+        L.d_tile_start = (uint32_t*)ctx->d_tstart;
+        L.ntiles = nmcu / TILE_MCUS;
+    }
     L.spin_ticks = ctx->spin_ticks;
     L.fault = ctx->fault;
     if (batch) {
@@ -536,14 +584,15 @@ extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nmcu = (size_t)mw * mcu_rows;
-    if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
+    const bool compact = want_compact(ctx, f, scan_len, nmcu);
+    if (!compact && (rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
     begin_call(ctx);
     if (!ctx->status_clean && !ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
     ctx->status_clean = false;
     mark(ctx, kpeg_hip_ctx::EV_BEGIN);
-    rc = run_entropy(ctx, f, d_scan, scan_len, (uint32_t)nmcu, (int16_t*)ctx->d_coef);
+    rc = run_entropy(ctx, f, d_scan, scan_len, (uint32_t)nmcu, (int16_t*)ctx->d_coef, nullptr, compact);
     if (rc) return rc;
-    rc = launch_idct(ctx, f, (const int16_t*)ctx->d_coef, d_rgb, mcu_rows);
+    rc = launch_idct(ctx, f, (const int16_t*)ctx->d_coef, d_rgb, mcu_rows, nullptr, 0, compact);
     if (rc) return rc;
     mark(ctx, kpeg_hip_ctx::EV_IDCT);
     return finish_async(ctx, ctx->idct_mode != 1);
@@ -586,6 +635,7 @@ static int ensure_lanes(kpeg_hip_ctx* ctx)
         ctx->lanes[l]->sync_passes = ctx->sync_passes;
         ctx->lanes[l]->warm = ctx->warm;
         ctx->lanes[l]->subseq = ctx->subseq;
+        ctx->lanes[l]->coef_layout = ctx->coef_layout;
     }
     for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
         if (!ctx->lane_ev[l]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
@@ -694,14 +744,15 @@ static int decode_batch_fused(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f,
         B.total_len = bytes;
         B.restart_interval = nmcu1;
         const size_t nmcu = (size_t)nmcu1 * n;
-        if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
+        const bool compact = want_compact(ctx, f, bytes, nmcu);
+        if (!compact && (rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 192 * sizeof(int16_t)))) return rc;
         begin_call(ctx);
         if (!ctx->status_clean) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
         ctx->status_clean = false;
-        rc = run_entropy(ctx, f, nullptr, 0, (uint32_t)nmcu, (int16_t*)ctx->d_coef, &B);
+        rc = run_entropy(ctx, f, nullptr, 0, (uint32_t)nmcu, (int16_t*)ctx->d_coef, &B, compact);
         if (rc) return rc;
         rc = launch_idct(ctx, f, (const int16_t*)ctx->d_coef, nullptr, (uint32_t)(f->height / 8) * n, (uint8_t* const*)(db + (size_t)n * 8),
-                         f->height / 8);
+                         f->height / 8, compact);
         if (rc) return rc;
         if ((rc = finish_async(ctx, true))) return rc;
         done += n;
@@ -929,7 +980,8 @@ extern "C" int kpeg_hip_decode_sharded_dev(kpeg_hip_ctx* const* ctxs, int ngpu, 
 // test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default),
 // key 3 = images per fused-batch chunk (0 = default), key 4 = sub-sequence size (0 = from the bit rate, else the sparse or the
 // dense size is forced), key 5 = bound of the device-side waits between workgroups in microseconds (0 = defaults), key 6 = fault
-// injection: bit 0 K0's, bit 1 the chained K1 pass's first workgroup never publishes (its successors must time out)
+// injection: bit 0 K0's, bit 1 the chained K1 pass's first workgroup never publishes (its successors must time out), key 7 = coefficient
+// layout between K2 and K4: 0 = chosen per call, 1 = always dense, 2 = the compact stream wherever it is possible
 extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
 {
     if (!ctx) return KPEG_HIP_E_ARG;
@@ -939,6 +991,7 @@ extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
     else if (key == 4) ctx->subseq = value;
     else if (key == 5) ctx->spin_ticks = value > 0 ? (unsigned long long)value * 100ull : 0ull;   // microseconds
     else if (key == 6) ctx->fault = (uint32_t)value;
+    else if (key == 7) ctx->coef_layout = value;
     else return KPEG_HIP_E_ARG;
     return KPEG_HIP_OK;
 }

@@ -490,18 +490,23 @@ def test_decode_batch_dev_and_error(ctx):
     ctx.sync()
 
 
-def test_bench_multi_gpu_path_rehearsal():
-    """bench.py's N>1 path (per-rank stripe synthesis with restart markers, DRI parse, stripe decode at a
-    row offset, gather) as a 2-rank gloo rehearsal on this one GPU, verified against the oracle."""
+@pytest.mark.parametrize("weak", [False, True])
+def test_bench_multi_gpu_path_rehearsal(weak):
+    """bench.py's N>1 path (per-rank stripe synthesis with restart markers, DRI parse, stripe decode at a row offset, the
+    banded decode + send to rank 0) as a 2-rank gloo rehearsal on this one GPU, verified against the oracle: the strong
+    mode (one image, its rows split over the ranks: BASELINE config 5's shape at a small size) and the --weak mode."""
     import os, socket, subprocess, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse",
-           "--width", "512", "--height", "256", "--no-cpu-baseline"]
+           "--width", "512", "--height", "256", "--no-cpu-baseline"] + (["--weak"] if weak else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, KPEG_BENCH_VERIFY="1"))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "VERIFY_OK" in out.stderr
     import json
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["gather"]["bytes"] == 512 * 256 * 3
+    rows_per_rank = 256 if weak else 128
+    assert d["n_gpus"] == 2 and d["scaling"] == ("weak" if weak else "strong")
+    assert d["gather"]["bytes_into_root"] == 512 * rows_per_rank * 3 and d["gather"]["bands_per_rank"] == 2
+    assert d["config"]["pixels_per_step"] == 512 * rows_per_rank * 2

@@ -75,6 +75,43 @@ def test_k0_look_back_falls_back_when_a_predecessor_never_publishes(ctx):
     assert np.array_equal(ctx.decode_scan(frame, scan), want)
 
 
+def test_k0_look_back_fallback_on_every_kind_of_chunk(ctx):
+    """Fault injection: no K0 workgroup publishes its aggregate ahead of its prefix, and the bound is 1 us: look-backs
+    compute many predecessors' aggregates from the input bytes themselves -- first, middle and last chunks, restart
+    markers on chunk edges, the images of a fused batch.  The results must not change."""
+    import torch
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 6, 4) == 0
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 5, 1) == 0
+    try:
+        for (w, h, interval, seed) in ((1024, 512, 0, 51), (1024, 512, 128, 52), (2048, 256, 3, 53), (512, 512, 1, 54)):
+            data = T.synth_jpeg(w, h, seed=seed, sigma=10.0, restart_interval=interval)
+            if interval:
+                want, p, _ = T.oracle_decode_rst(data, interval)
+            else:
+                st, want = T.oracle_decode(data)
+                p = T.oracle_parse(data)
+            assert len(p.scan) > 5 * 4096
+            got = ctx.decode_scan(T.make_frame(p, interval), p.scan)
+            assert np.array_equal(got, want), (w, h, interval)
+        frames, scans, wants = None, [], []
+        for i in range(6):
+            data = T.synth_jpeg(320, 200, seed=70 + i, sigma=12.0)
+            st, want = T.oracle_decode(data)
+            p = T.oracle_parse(data)
+            frames = T.make_frame(p)
+            scans.append(torch.frombuffer(bytearray(p.scan), dtype=torch.uint8).cuda())
+            wants.append(want)
+        outs = [torch.zeros((200, 320, 3), dtype=torch.uint8, device="cuda") for _ in scans]
+        torch.cuda.synchronize()
+        ctx.decode_batch_dev(frames, [t.data_ptr() for t in scans], [t.numel() for t in scans], [t.data_ptr() for t in outs])
+        ctx.sync()
+        for i, o in enumerate(outs):
+            assert np.array_equal(o.cpu().numpy(), wants[i]), i
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 5, 0)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 6, 0)
+
+
 _CHAIN = r"""
 import sys
 sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
