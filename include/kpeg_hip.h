@@ -86,11 +86,11 @@ int kpeg_hip_create(kpeg_hip_ctx** ctx, int device);
 void kpeg_hip_destroy(kpeg_hip_ctx* ctx);
 const char* kpeg_hip_strerror(int code);
 const char* kpeg_hip_last_error(const kpeg_hip_ctx* ctx);
-/* Launch on a caller-owned hipStream_t (e.g. PyTorch's current stream); NULL = the context's own (non-blocking)
- * stream.  NOTE: the legacy default stream's handle IS NULL (PyTorch's default stream reports 0): to launch on it, and so
- * stay ordered with a framework's default-stream work, pass KPEG_HIP_STREAM_LEGACY (= hipStreamLegacy).  Work queued on
- * the stream in use before the switch is waited for by the new stream (the scratch buffers are shared). */
-#define KPEG_HIP_STREAM_LEGACY ((void*)1)
+/* Launch on a caller-owned hipStream_t (created with hipStreamCreate*; e.g. a PyTorch side stream); NULL = the
+ * context's own non-blocking stream.  NOTE: the legacy default stream's handle IS NULL (PyTorch's default stream reports
+ * 0), so it cannot be selected here: a caller whose buffers are produced on the default stream either synchronises before
+ * the call or does that work on a created stream and passes it.  Work queued on the stream in use before the switch is
+ * waited for by the new stream (the scratch buffers are shared). */
 int kpeg_hip_set_stream(kpeg_hip_ctx* ctx, void* hip_stream);
 /* Wait for the context's stream and return the deferred status of the last *_dev call
  * (kernels report corrupt entropy data through a device-side flag). */

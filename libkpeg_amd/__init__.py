@@ -146,11 +146,13 @@ class Context:
 
     # -- knobs
     def set_stream(self, hip_stream):
-        """hip_stream: a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream.  PyTorch's default stream reports
-        handle 0 = the legacy default stream, which the C ABI spells KPEG_HIP_STREAM_LEGACY (its NULL means "the context's
-        own stream", which is NOT ordered with default-stream work): mapped here, so that tensors produced by torch ops just
-        before a call are complete when the kernels read them."""
-        self._chk(self.lib.kpeg_hip_set_stream(self._h, ctypes.c_void_p(hip_stream if hip_stream else 1)))
+        """hip_stream: a hipStream_t handle of a CREATED stream, e.g. torch.cuda.Stream().cuda_stream.  PyTorch's default
+        stream reports handle 0, which the C ABI reads as "the context's own stream" -- NOT ordered with default-stream
+        work (a tensor written by a torch op just before the call may not be complete when the kernels read it): refused
+        here; run the torch side under `torch.cuda.stream(s)` / `torch.cuda.set_stream(s)` and pass that stream."""
+        if not hip_stream:
+            raise ValueError("the default stream (handle 0) cannot be selected: use a created stream, or use_own_stream()")
+        self._chk(self.lib.kpeg_hip_set_stream(self._h, ctypes.c_void_p(hip_stream)))
 
     def use_own_stream(self):
         self._chk(self.lib.kpeg_hip_set_stream(self._h, ctypes.c_void_p(0)))

@@ -784,7 +784,9 @@ struct RunResult {
 #endif
 };
 
-// Sync/count run: decode from `s` until the bit position reaches `pend`.
+// Sync/count run: decode from `s` until the bit position reaches `pend`.  COUNT: also count the records of the compact
+// coefficient stream (left out where the dense layout is written: K1 is the pipeline's longest kernel).
+template <bool COUNT>
 __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend)
 {
     BitReader br;
@@ -805,7 +807,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
         const bool adv = kraw >= 64;   // this table's turn ends: DC symbol, EOB, 63rd coefficient (Decoder.cpp:759)
         // exactly K2's condition for storing an AC coefficient, minus its check that the block lies inside the segment
         // (K2 never emits more records than are counted here: the counts fix where every lane's records go)
-        nrec += ((e >> 26) & 1u) & q & (kraw <= 64 ? 1u : 0u);
+        if (COUNT) nrec += ((e >> 26) & 1u) & q & (kraw <= 64 ? 1u : 0u);
         k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
         q = adv ? ((e >> 25) & 1u) : q;
         tb += adv ? LUT_BYTES : 0u;
@@ -927,7 +929,7 @@ __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list,
 // Scan of (nb, dc0, dc1, dc2): workgroup totals -> exclusive prefix, by one workgroup of K1's last
 // launch (SYNC_WG threads; s = SYNC_WG int4 of LDS); also the call's bookkeeping: blocks found, passes
 // used, K0's look-back words cleared for the next call.
-template <int S>
+template <int S, bool COUNT>
 __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_t* status, int pass, bool rippling, unsigned long long* part,
                           uint32_t nparts, int4* s, int4* carry)
 {
@@ -966,7 +968,7 @@ __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_
     uint32_t* rc = reinterpret_cast<uint32_t*>(carry) + 1;   // (carry->x is read below: a word beside it)
     if (t == 0) *rc = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < nw; base += SYNC_WG) {
+    for (uint32_t base = 0; COUNT && base < nw; base += SYNC_WG) {
         const uint32_t i = base + t;
         const uint32_t v = i < nw ? __hip_atomic_load(&wrec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         sr[t] = v;
@@ -1003,7 +1005,7 @@ __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_
 //   the stream needs more than WARM_BITS to re-synchronise.
 // Pass p >= 1: a workgroup whose assumed entry state differs from its predecessor's real exit
 //   state re-decodes from that state and the change ripples on.
-template <int S>
+template <int S, bool COUNT>
 __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 {
     KPEG_GEOMETRY(S);
@@ -1026,7 +1028,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
     const bool rippling = p >= 2 && a.meta->moved[p - 1] != 0;
     if (a.chained && !rippling) {
-        if (g == 0) wsum_scan<S>(a.wsum, a.wrec, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (g == 0) wsum_scan<S, COUNT>(a.wsum, a.wrec, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
         return;
     }
     if (a.chained) {
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s_n[0] = atomicAdd(&a.meta->ticket, 1u) == (nsub + OWN - 1) / OWN - 1 ? 1u : 0u;
         }
         __syncthreads();
-        if (s_n[0]) wsum_scan<S>(a.wsum, a.wrec, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (s_n[0]) wsum_scan<S, COUNT>(a.wsum, a.wrec, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
     };
     const uint64_t* Xb_prev = a.Xb + (size_t)((p & 1) ^ 1) * a.nwg_cap;
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
@@ -1128,7 +1130,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 s.c = 0;
                 s.k = 0;
                 s.q = 0;
-                const RunResult r = run_count(T, s_bits, w0, s, geo.pend);
+                const RunResult r = run_count<COUNT>(T, s_bits, w0, s, geo.pend);
 #if KPEG_SYNC_STATS
                 st_runs++;
                 st_iters += r.iters;
@@ -1136,7 +1138,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 s_X[j + 1] = r.exit_state;
                 if (j >= wu) {
                     s_cnt[j - wu] = r.cnt;
-                    s_nrec[j - wu] = r.nrec;
+                    if (COUNT) s_nrec[j - wu] = r.nrec;
                 }
                 want = geo.li != 0 && j > 0;
             }
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
             s_X[j + 1] = a.X[i0 + j];
             s_cnt[j] = a.cnt[i0 + j];
-            s_nrec[j] = a.nrec[i0 + j];
+            if (COUNT) s_nrec[j] = a.nrec[i0 + j];
         }
         if (t == 0) {
             s_X[0] = entry;
@@ -1207,7 +1209,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 // exit state yet: either value is a valid start, and if it moved this item is on
                 // the next list again
                 const uint64_t before = s_X[j + 1];   // (read with the entry state: one LDS round trip, not two)
-                const RunResult r = run_count(T, s_bits, w0, unpack_state(s_X[j]), s_geo[j] & 0x7FFFFFFFu);
+                const RunResult r = run_count<COUNT>(T, s_bits, w0, unpack_state(s_X[j]), s_geo[j] & 0x7FFFFFFFu);
 #if KPEG_SYNC_STATS
                 st_runs++;
                 st_iters += r.iters;
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 s_X[j + 1] = r.exit_state;
                 if (j >= wu) {
                     s_cnt[j - wu] = r.cnt;
-                    s_nrec[j - wu] = r.nrec;
+                    if (COUNT) s_nrec[j - wu] = r.nrec;
                 }
                 want = changed && j + 1 < nit && !(s_geo[j + 1] >> 31);
             }
@@ -1245,8 +1247,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         a.X[i0 + t] = s_X[wu + t + 1];
         tot = s_cnt[t];
         a.cnt[i0 + t] = tot;
-        trec = s_nrec[t];
-        a.nrec[i0 + t] = trec;
+        if (COUNT) {
+            trec = s_nrec[t];
+            a.nrec[i0 + t] = trec;
+        }
     }
     // per-workgroup totals for the scan
     for (int o = 32; o > 0; o >>= 1) {
@@ -1780,7 +1784,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     for (int t = 0; t < npass; ++t) {
         sa.pass = t;
         sa.chained = t == npass - 1 ? 1 : 0;
-        hipLaunchKernelGGL(k_sync_pass<SB>, dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        if (L.d_tile_start) hipLaunchKernelGGL((k_sync_pass<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        else hipLaunchKernelGGL((k_sync_pass<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
     }
     mark(2);
 

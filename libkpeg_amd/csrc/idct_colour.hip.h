@@ -572,6 +572,9 @@ __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, 
 #ifndef KPEG_K4_MAX3
 #define KPEG_K4_MAX3 0
 #endif
+#ifndef KPEG_K4_STASH_DENSE
+#define KPEG_K4_STASH_DENSE 1   // dense layout: queue entries carry their blocks' corner words too (0: the fix-up pass loads them)
+#endif
 #ifndef KPEG_K4_CHROMA2
 #define KPEG_K4_CHROMA2 0
 #endif
@@ -606,7 +609,7 @@ __device__ unsigned long long g_k4_stamp[8192 * 4];
 template <bool COMPACT>
 __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, QTables qt)
 {
-    constexpr int QW = QUEUE_WORDS_COMPACT;   // both layouts stash the blocks' corner words in the queue entry
+    constexpr int QW = (COMPACT || KPEG_K4_STASH_DENSE) ? QUEUE_WORDS_COMPACT : QUEUE_WORDS;   // entries that stash the blocks' corner words are twice as long
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_all[K4_WAVES][8 * TILE_ROW_STRIDE];
     __shared__ __attribute__((aligned(16))) uint32_t s_queue_all[K4_WAVES][QUEUE_CAP * QW];
     __shared__ __attribute__((aligned(16))) uint32_t s_img_all[COMPACT ? K4_WAVES : 1][IMG_BYTES / 4];
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             // A queue entry carries the corner words of its three blocks (stashed when it was pushed: no load, no memory latency
             // in this pass); an overflow-list pixel has none: dense layout -> two 4-byte loads per block, compact stream -> the
             // general way (from the tile's image).
-            const bool from_queue = valid && e < nq;
+            const bool from_queue = valid && e < nq && (COMPACT || KPEG_K4_STASH_DENSE);
             const bool stashed = !COMPACT || from_queue;
             const bool cn0 = need0 && (pos & (1u << 9)) && stashed, cn1 = need1 && (pos & (1u << 10)) && stashed, cn2 = need2 && (pos & (1u << 11)) && stashed;
 #endif
@@ -1089,10 +1092,14 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         // The first word of rows 0 and 1 of the MCU's three blocks (coefficients (0,0),(0,1) and (1,0),(1,1)): they sit on
         // lanes 0 and 4 of the group.  A queued pixel takes them along, so the fix-up pass settles corner-only blocks (nine
         // unsafe samples in ten) without touching memory.
+        constexpr bool STASH = COMPACT || KPEG_K4_STASH_DENSE;
         const int lrow0 = tid & 56, lrow1 = lrow0 | 4;
-        const uint32_t cw00 = (uint32_t)__shfl((int)d0.x, lrow0), cw01 = (uint32_t)__shfl((int)d0.x, lrow1);
-        const uint32_t cw10 = (uint32_t)__shfl((int)d1.x, lrow0), cw11 = (uint32_t)__shfl((int)d1.x, lrow1);
-        const uint32_t cw20 = (uint32_t)__shfl((int)d2.x, lrow0), cw21 = (uint32_t)__shfl((int)d2.x, lrow1);
+        uint32_t cw00 = 0, cw01 = 0, cw10 = 0, cw11 = 0, cw20 = 0, cw21 = 0;
+        if constexpr (STASH) {
+            cw00 = (uint32_t)__shfl((int)d0.x, lrow0), cw01 = (uint32_t)__shfl((int)d0.x, lrow1);
+            cw10 = (uint32_t)__shfl((int)d1.x, lrow0), cw11 = (uint32_t)__shfl((int)d1.x, lrow1);
+            cw20 = (uint32_t)__shfl((int)d2.x, lrow0), cw21 = (uint32_t)__shfl((int)d2.x, lrow1);
+        }
         const size_t cur_off = tile_offset(trow, m0);
         if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
         have_prev = true;
@@ -1229,7 +1236,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
 #endif
 #endif
                             // the 2x2 corner of the pixel's three blocks (rows 0 and 1, columns 0 and 1)
-                            q[8] = cw00, q[9] = cw01, q[10] = cw10, q[11] = cw11, q[12] = cw20, q[13] = cw21;
+                            if constexpr (STASH) q[8] = cw00, q[9] = cw01, q[10] = cw10, q[11] = cw11, q[12] = cw20, q[13] = cw21;
                         } else {
                             s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
                         }

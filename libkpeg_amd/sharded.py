@@ -24,7 +24,12 @@ def gpu_stripe_decoder(ctx):
     def decode(frame, scan_slice, first_row, rows):
         d_scan = torch.from_numpy(np.ascontiguousarray(scan_slice)).cuda()
         d_rgb = torch.empty((rows * 8, frame.width, 3), dtype=torch.uint8, device="cuda")
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        h = torch.cuda.current_stream().cuda_stream
+        if h:
+            ctx.set_stream(h)            # ordered with the torch ops around it
+        else:
+            torch.cuda.synchronize()     # default stream (handle 0): the context keeps its own stream, so wait for the upload
+            ctx.use_own_stream()
         ctx.decode_stripe_dev(frame, d_scan.data_ptr(), d_scan.numel(), first_row, rows, d_rgb.data_ptr())
         ctx.sync()
         return d_rgb

@@ -38,6 +38,7 @@ def main():
     args = ap.parse_args()
     import torch
     import libkpeg_amd as K
+    torch.cuda.set_stream(torch.cuda.Stream())   # a created stream: the default stream's handle 0 cannot be handed to the C ABI
 
     libs = {}
     for f in sorted(glob.glob(os.path.join(ROOT, "build", "ablate", "libkpeg_hip_*.so"))):

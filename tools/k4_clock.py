@@ -18,6 +18,7 @@ import bench  # noqa: E402
 def main():
     import torch
     import libkpeg_amd as K
+    torch.cuda.set_stream(torch.cuda.Stream())   # a created stream: the default stream's handle 0 cannot be handed to the C ABI
     lib = K.load_variant(os.path.join(ROOT, "build", "ablate", "libkpeg_hip_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "stamp")))
     W, H = bench.W8K, bench.H8K
     rc, frame, scan = K.host_parse(bench.synth_jpeg(W, H))
