@@ -16,8 +16,9 @@ f=$(ls $out/stats/*kernel_stats.csv $out/stats/*/*kernel_stats.csv 2>/dev/null |
 cp "$f" $out/kernel_stats.csv
 rm -rf $out/stats
 head -12 $out/kernel_stats.csv
+# HBM traffic of K4 on the SAME command the bench line comes from (the whole decode, not K4 alone): separate passes per counter
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --idct-only > $out/pmc_$c.log 2>&1 || true
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || true
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
@@ -31,8 +32,9 @@ m = {k: sum(v) / len(v) for k, v in agg.items()}
 if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
     fetch = m['FETCH_SIZE'] * 1024 * 2   # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md)
     write = m['WRITE_SIZE'] * 1024
-    json.dump({"kernel": "k_idct_colour_fast", "workload": "7680x4320 q75 (bench.py --idct-only)", "FETCH_SIZE_KB": m['FETCH_SIZE'],
+    json.dump({"kernel": "k_idct_colour_fast", "workload": "7680x4320 q75, inside the whole decode (bench.py --steps 5 --warmup 2 --no-cpu-baseline)", "FETCH_SIZE_KB": m['FETCH_SIZE'],
                "WRITE_SIZE_KB": m['WRITE_SIZE'], "fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write,
+               "launches_averaged": len(agg.get('FETCH_SIZE', [])),
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_round.sh); FETCH_SIZE doubled: on gfx950 it "
                        "reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section). Algorithmic bytes 298.6 MB + 6.2 MB of error bounds."},
               open(out + '/k4_traffic.json', 'w'), indent=1)
