@@ -11,6 +11,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,16 @@ namespace kpeg
             void adoptRGB8( std::vector<UInt8>&& rgb );
             const std::vector<UInt8>& getRGB8() const;
 
+            /// A consumer of row bands (first row, rows, rows*width*3 bytes R,G,B); false stops the source.
+            typedef std::function<bool( std::size_t, std::size_t, const UInt8* )> BandSink;
+            /// The pixels stay where the decoder left them (GPU memory) until somebody wants them: `source` streams them
+            /// band by band into a sink.  dumpRawData() hands the bands straight to the file (the next band crosses PCIe
+            /// while one is written); getRGB8() / getPixelPtr() assemble them first.  Replaces the reference's
+            /// vector<vector<Pixel>> materialisation (src/Image.cpp:49-70), which at GPU speed was most of the time.
+            void setLazySource( std::function<bool( const BandSink& )> source );
+            /// Fetches the pixels now if they are still with the decoder (idempotent).
+            bool materialise() const;
+
         private:
             std::string  filename_;
             PixelPtr     pixelPtr_;
@@ -55,7 +66,8 @@ namespace kpeg
             std::string  comment_;
             std::size_t  width_;
             std::size_t  height_;
-            std::vector<UInt8> rgb8_;
+            mutable std::vector<UInt8> rgb8_;
+            mutable std::function<bool( const BandSink& )> lazy_;
     };
 
     const std::string valueToBitString( const Int16 value );

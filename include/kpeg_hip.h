@@ -117,6 +117,15 @@ int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const int16
 int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len,
                          uint8_t* rgb);
 
+/* The same decode with the pixels left on the device, in a buffer the context owns (valid until the context's next
+ * decode), and their download in row bands through two pinned bounce buffers: while band k+1 crosses PCIe, `sink` is
+ * called with band k (from the calling thread), e.g. to fwrite it -- Image::dumpRawData's 99.5 MB (8K) then reach the
+ * file without ever being assembled in pageable memory (reference sink: src/Image.cpp:108-140).  band_rows = 0 picks
+ * bands of about 8 MiB.  sink returns non-zero to abort (KPEG_HIP_E_ARG is returned). */
+typedef int (*kpeg_hip_band_sink)(void* user, uint32_t first_row, uint32_t rows, const uint8_t* rgb, size_t bytes);
+int kpeg_hip_decode_scan_resident(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len);
+int kpeg_hip_download_bands(kpeg_hip_ctx* ctx, const kpeg_frame* frame, uint32_t band_rows, kpeg_hip_band_sink sink, void* user);
+
 /* `count` independent images of identical geometry and tables (throughput mode, BASELINE config 4; the
  * reference's counterpart is a loop over JPEGDecoder::decodeImageFile, src/main.cpp:19-33).  Chunks of
  * images alternate between two internal lanes (stream + buffers + pinned staging each): a chunk's scans go

@@ -51,12 +51,15 @@ class Timings(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+BAND_SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
+
 EXPORTS = [
     "kpeg_hip_abi_version", "kpeg_hip_build_hash", "kpeg_hip_create", "kpeg_hip_destroy", "kpeg_hip_strerror", "kpeg_hip_last_error",
     "kpeg_hip_set_stream", "kpeg_hip_sync", "kpeg_hip_set_profiling", "kpeg_hip_get_timings",
     "kpeg_hip_idct_colour", "kpeg_hip_decode_scan", "kpeg_hip_decode_batch", "kpeg_hip_decode_batch_dev",
     "kpeg_hip_idct_colour_dev", "kpeg_hip_decode_scan_dev", "kpeg_hip_decode_stripe_dev",
     "kpeg_hip_entropy_decode_dev", "kpeg_hip_set_idct_mode", "kpeg_hip_decode_sharded", "kpeg_hip_decode_sharded_dev",
+    "kpeg_hip_decode_scan_resident", "kpeg_hip_download_bands",
 ]
 
 _lib = None
@@ -112,6 +115,9 @@ def _declare(L):
     L.kpeg_hip_decode_scan_dev.argtypes = [vp, FP, vp, sz, vp]
     L.kpeg_hip_decode_stripe_dev.argtypes = [vp, FP, vp, sz, ctypes.c_uint32, ctypes.c_uint32, vp]
     L.kpeg_hip_entropy_decode_dev.argtypes = [vp, FP, vp, sz, vp]
+    if hasattr(L, "kpeg_hip_download_bands"):
+        L.kpeg_hip_decode_scan_resident.argtypes = [vp, FP, vp, sz]
+        L.kpeg_hip_download_bands.argtypes = [vp, FP, ctypes.c_uint32, BAND_SINK, vp]
     if hasattr(L, "kpeg_hip_decode_sharded"):   # (reference builds of earlier trees kept for A/B runs lack the newer entries)
         L.kpeg_hip_decode_sharded.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
         L.kpeg_hip_decode_sharded_dev.argtypes = [ctypes.POINTER(vp), c_int, FP, vp, sz, vp]
@@ -186,6 +192,22 @@ class Context:
         rgb = np.empty((frame.height, frame.width, 3), np.uint8)
         self._chk(self.lib.kpeg_hip_decode_scan(self._h, ctypes.byref(frame), scan.ctypes.data, scan.size, rgb.ctypes.data))
         return rgb
+
+    def decode_scan_banded(self, frame, scan, band_rows=0):
+        """kpeg_hip_decode_scan_resident + kpeg_hip_download_bands; returns (HxWx3 array assembled from the bands, band list)."""
+        scan = np.frombuffer(scan, dtype=np.uint8) if not isinstance(scan, np.ndarray) else scan
+        self._chk(self.lib.kpeg_hip_decode_scan_resident(self._h, ctypes.byref(frame), scan.ctypes.data, scan.size))
+        rgb = np.empty((frame.height, frame.width, 3), np.uint8)
+        bands = []
+
+        def sink(user, row0, rows, ptr, nbytes):
+            rgb[row0:row0 + rows] = np.ctypeslib.as_array(ptr, shape=(nbytes,)).reshape(rows, frame.width, 3)
+            bands.append((row0, rows))
+            return 0
+
+        cb = BAND_SINK(sink)
+        self._chk(self.lib.kpeg_hip_download_bands(self._h, ctypes.byref(frame), band_rows, cb, None))
+        return rgb, bands
 
     def decode_batch(self, frame, scans):
         """scans: list of byte strings / uint8 arrays of one geometry and one set of tables. Returns a list of HxWx3 uint8."""

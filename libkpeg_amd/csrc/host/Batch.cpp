@@ -101,6 +101,7 @@ namespace kpeg
 
         std::string why;
         kpeg_hip_ctx* ctx = hip::context( &why );
+        hip::claimResident( nullptr );   // an image a JPEGDecoder left on the GPU is fetched before the batch reuses the buffers
         if ( !ctx )
         {
             LOG(Logger::Level::ERROR) << "[ FATAL ] " << why << std::endl;

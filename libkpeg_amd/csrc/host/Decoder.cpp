@@ -38,6 +38,7 @@ namespace kpeg
 
     JPEGDecoder::~JPEGDecoder()
     {
+        hip::releaseResident( &image_ );   // (pixels left on the GPU die with the decoder)
         close();
         LOG(Logger::Level::INFO) << "Destroyed \'JPEGDecoder object\'." << std::endl;
     }
@@ -427,20 +428,47 @@ namespace kpeg
             LOG(Logger::Level::ERROR) << "[ FATAL ] " << why << std::endl;
             return ERROR;
         }
-        std::vector<UInt8> rgb( (std::size_t)w * h * 3 );
         int rc;
         const std::vector<kpeg_hip_ctx*>& many = f.restart_interval ? hip::contexts( &why ) : std::vector<kpeg_hip_ctx*>();
         if ( many.size() > 1 && ( w / 8 ) % f.restart_interval == 0 )   // every MCU row starts a restart interval
-            // extension (the reference rejects DRI): a restart-interval image goes over $KPEG_HIP_DEVICES GPUs as row stripes
+        {
+            // extension (the reference rejects DRI): a restart-interval image goes over $KPEG_HIP_DEVICES GPUs as row stripes,
+            // every GPU downloads its own rows
+            std::vector<UInt8> rgb( (std::size_t)w * h * 3 );
             rc = kpeg_hip_decode_sharded( many.data(), (int)many.size(), &f, scan_.data(), scan_.size(), rgb.data() );
+            if ( rc == KPEG_HIP_OK )
+                image_.adoptRGB8( std::move( rgb ) );
+        }
         else
-            rc = kpeg_hip_decode_scan( ctx, &f, scan_.data(), scan_.size(), rgb.data() );
+        {
+            // The pixels stay on the GPU until somebody asks for them (Image::setLazySource): dumpRawData() then streams
+            // them to the file in bands through pinned buffers.  A later decode on the shared context would overwrite
+            // them: whoever decodes next fetches a still pending image first (hip::claimResident).
+            hip::claimResident( &image_ );
+            rc = kpeg_hip_decode_scan_resident( ctx, &f, scan_.data(), scan_.size() );
+            if ( rc == KPEG_HIP_OK )
+            {
+                Image* self = &image_;
+                image_.setLazySource( [ctx, f, self]( const Image::BandSink& sink ) {
+                    struct Tramp
+                    {
+                        static int call( void* user, uint32_t row0, uint32_t rows, const uint8_t* p, size_t )
+                        {
+                            return ( *static_cast<const Image::BandSink*>( user ) )( row0, rows, p ) ? 0 : 1;
+                        }
+                    };
+                    (void)self;
+                    return kpeg_hip_download_bands( ctx, &f, 0, &Tramp::call, const_cast<Image::BandSink*>( &sink ) ) == KPEG_HIP_OK;
+                } );
+            }
+            else
+                hip::releaseResident( &image_ );
+        }
         if ( rc != KPEG_HIP_OK )
         {
             LOG(Logger::Level::ERROR) << "[ FATAL ] GPU decode failed: " << kpeg_hip_strerror( rc ) << ": " << kpeg_hip_last_error( ctx ) << std::endl;
             return ERROR;
         }
-        image_.adoptRGB8( std::move( rgb ) );
         return SUCCESS;
     }
 }

@@ -39,6 +39,24 @@ namespace kpeg
             return h.ctx;
         }
 
+        namespace
+        {
+            Image* g_resident = nullptr;
+        }
+
+        void claimResident( Image* owner )
+        {
+            if ( g_resident && g_resident != owner )
+                g_resident->materialise();   // the device buffer is about to be reused
+            g_resident = owner;
+        }
+
+        void releaseResident( Image* owner )
+        {
+            if ( g_resident == owner )
+                g_resident = nullptr;
+        }
+
         const std::vector<kpeg_hip_ctx*>& contexts( std::string* why )
         {
             struct Many

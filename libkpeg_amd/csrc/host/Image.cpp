@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <memory>
 
 #include "Logger.hpp"
 
@@ -40,13 +41,45 @@ namespace kpeg
     void Image::adoptRGB8( std::vector<UInt8>&& rgb )
     {
         rgb8_ = std::move( rgb );
+        lazy_ = nullptr;
         pixelPtr_.reset();
     }
 
-    const std::vector<UInt8>& Image::getRGB8() const { return rgb8_; }
+    void Image::setLazySource( std::function<bool( const BandSink& )> source )
+    {
+        rgb8_.clear();
+        pixelPtr_.reset();
+        lazy_ = std::move( source );
+    }
+
+    bool Image::materialise() const
+    {
+        if ( !lazy_ )
+            return true;
+        // bands arrive in row order: appended to a reserved vector (no zero fill, one copy)
+        rgb8_.clear();
+        rgb8_.reserve( width_ * height_ * 3 );
+        const std::size_t pitch = width_ * 3;
+        auto source = std::move( lazy_ );
+        lazy_ = nullptr;
+        const bool ok = source( [&]( std::size_t, std::size_t rows, const UInt8* p ) {
+            rgb8_.insert( rgb8_.end(), p, p + rows * pitch );
+            return true;
+        } );
+        if ( !ok || rgb8_.size() != width_ * height_ * 3 )
+            rgb8_.clear();
+        return ok;
+    }
+
+    const std::vector<UInt8>& Image::getRGB8() const
+    {
+        materialise();
+        return rgb8_;
+    }
 
     PixelPtr Image::getPixelPtr()
     {
+        materialise();
         if ( !pixelPtr_ && rgb8_.size() == width_ * height_ * 3 && !rgb8_.empty() )
         {
             pixelPtr_ = std::make_shared<std::vector<std::vector<Pixel>>>( height_, std::vector<Pixel>( width_ ) );
@@ -70,7 +103,7 @@ namespace kpeg
     const bool Image::dumpRawData( const std::string& filename )
     {
         const bool haveRGB = !rgb8_.empty() && rgb8_.size() == width_ * height_ * 3;
-        if ( !haveRGB && pixelPtr_ == nullptr )
+        if ( !haveRGB && pixelPtr_ == nullptr && !lazy_ )
         {
             LOG(Logger::Level::ERROR) << "Unable to create dump file \'" + filename + "\', Invalid pixel pointer" << std::endl;
             return false;
@@ -85,7 +118,15 @@ namespace kpeg
         std::fprintf( f, "P6\n# PPM dump created using libKPEG: https://github.com/TheIllusionistMirage/libKPEG\n%zu %zu\n255\n",
                       width_, height_ );
         bool ok = true;
-        if ( haveRGB )
+        if ( lazy_ && !haveRGB )
+        {
+            // the pixels are still with the decoder: band k is written while band k + 1 is on its way; nothing is assembled
+            std::setvbuf( f, nullptr, _IONBF, 0 );   // (whole bands go down in one write each)
+            const std::size_t pitch = width_ * 3;
+            auto source = lazy_;   // (kept: the file is one consumer; a later getPixelPtr() may still want the pixels)
+            ok = source( [&]( std::size_t, std::size_t rows, const UInt8* p ) { return std::fwrite( p, 1, rows * pitch, f ) == rows * pitch; } );
+        }
+        else if ( haveRGB )
             ok = std::fwrite( rgb8_.data(), 1, rgb8_.size(), f ) == rgb8_.size();
         else
             for ( auto&& row : *pixelPtr_ )

@@ -83,6 +83,9 @@ struct kpeg_hip_ctx {
     hipEvent_t lane_ev[NLANES + 1] = {};   // [NLANES] = fork point on the parent's stream
     bool lanes_pending = false;            // parent: lanes hold deferred status
     bool keep_status = false;              // lane, during a batch: the device status words accumulate over the lane's images
+    void* h_band[2] = {nullptr, nullptr};  // kpeg_hip_download_bands: pinned bounce buffers
+    hipEvent_t h_band_ev[2] = {nullptr, nullptr};
+    size_t h_band_cap = 0;
     void* h_scan = nullptr;                // lane: pinned staging for host-buffer batches
     void* d_batch = nullptr;               // fused batch: descriptor blob (pointer tables, lengths)
     size_t batch_cap = 0;
@@ -212,6 +215,10 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
         if (ctx->lanes[l]) kpeg_hip_destroy(ctx->lanes[l]);
     for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
         if (ctx->lane_ev[l]) (void)hipEventDestroy(ctx->lane_ev[l]);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->h_band[i]) (void)hipHostFree(ctx->h_band[i]);
+        if (ctx->h_band_ev[i]) (void)hipEventDestroy(ctx->h_band_ev[i]);
+    }
     if (ctx->h_scan) (void)hipHostFree(ctx->h_scan);
     for (int i = 0; i < 2; ++i) {
         if (ctx->h_batch[i]) (void)hipHostFree(ctx->h_batch[i]);
@@ -619,6 +626,69 @@ extern "C" int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(rgb, ctx->d_rgb, rbytes, hipMemcpyDeviceToHost, ctx->stream));
     return kpeg_hip_sync(ctx);
+}
+
+extern "C" int kpeg_hip_decode_scan_resident(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* scan, size_t scan_len)
+{
+    int rc = check_frame(ctx, f);
+    if (rc) return rc;
+    if (!scan || !scan_len) return KPEG_HIP_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t rbytes = (size_t)f->width * f->height * 3;
+    if ((rc = grow(ctx, &ctx->d_scan, &ctx->scan_cap, scan_len + 64))) return rc;
+    if ((rc = grow(ctx, &ctx->d_rgb, &ctx->rgb_cap, rbytes))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_scan, scan, scan_len, hipMemcpyHostToDevice, ctx->stream));
+    rc = kpeg_hip_decode_scan_dev(ctx, f, (const uint8_t*)ctx->d_scan, scan_len, (uint8_t*)ctx->d_rgb);
+    if (rc) return rc;
+    return kpeg_hip_sync(ctx);
+}
+
+extern "C" int kpeg_hip_download_bands(kpeg_hip_ctx* ctx, const kpeg_frame* f, uint32_t band_rows, kpeg_hip_band_sink sink, void* user)
+{
+    int rc = check_frame(ctx, f);
+    if (rc) return rc;
+    if (!sink) return KPEG_HIP_E_ARG;
+    const size_t pitch = (size_t)f->width * 3, rbytes = pitch * f->height;
+    if (!ctx->d_rgb || ctx->rgb_cap < rbytes) {
+        ctx->last_error = "no decoded image of this size is resident (kpeg_hip_decode_scan_resident first)";
+        return KPEG_HIP_E_ARG;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (band_rows == 0) band_rows = (uint32_t)std::max<size_t>(8, (((size_t)8 << 20) / pitch) & ~(size_t)7);
+    band_rows = std::min(band_rows, f->height);
+    const size_t bbytes = pitch * band_rows;
+    if (bbytes > ctx->h_band_cap) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->h_band[i]) (void)hipHostFree(ctx->h_band[i]);
+            ctx->h_band[i] = nullptr;
+        }
+        ctx->h_band_cap = 0;
+        for (int i = 0; i < 2; ++i) HIPCHK(ctx, hipHostMalloc(&ctx->h_band[i], bbytes, hipHostMallocDefault));
+        ctx->h_band_cap = bbytes;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->h_band_ev[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->h_band_ev[i], hipEventDisableTiming));
+    const uint32_t nb = (f->height + band_rows - 1) / band_rows;
+    auto rows_of = [&](uint32_t k) { return std::min(band_rows, f->height - k * band_rows); };
+    auto issue = [&](uint32_t k) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(ctx->h_band[k & 1], (const uint8_t*)ctx->d_rgb + (size_t)k * band_rows * pitch, pitch * rows_of(k),
+                                      hipMemcpyDeviceToHost, ctx->stream);
+        return e != hipSuccess ? e : hipEventRecord(ctx->h_band_ev[k & 1], ctx->stream);
+    };
+    auto deliver = [&](uint32_t k) -> int {
+        if (hipEventSynchronize(ctx->h_band_ev[k & 1]) != hipSuccess) return KPEG_HIP_E_DEVICE;
+        return sink(user, k * band_rows, rows_of(k), (const uint8_t*)ctx->h_band[k & 1], pitch * rows_of(k)) ? KPEG_HIP_E_ARG : KPEG_HIP_OK;
+    };
+    HIPCHK(ctx, issue(0));
+    for (uint32_t k = 1; k < nb; ++k) {
+        HIPCHK(ctx, issue(k));                   // band k crosses PCIe ...
+        if ((rc = deliver(k - 1))) break;        // ... while the sink has band k - 1
+    }
+    if (!rc) rc = deliver(nb - 1);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (rc == KPEG_HIP_E_ARG) ctx->last_error = "the band sink stopped the download";
+    return rc;
 }
 
 static int ensure_lanes(kpeg_hip_ctx* ctx)

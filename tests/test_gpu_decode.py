@@ -561,3 +561,18 @@ def test_one_4k_image_three_times(ctx, q, sigma, layout):
             assert np.array_equal(ctx.decode_scan(f, p.scan), want), rep
     finally:
         ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+
+
+@pytest.mark.parametrize("band_rows", [0, 8, 24, 1000])
+def test_resident_decode_and_banded_download(ctx, band_rows):
+    """kpeg_hip_decode_scan_resident + kpeg_hip_download_bands (what Image::dumpRawData streams to the PPM): the bands, put
+    together, are the decode; band sizes that do not divide the height, one band for the whole image, the default size."""
+    data = T.synth_jpeg(640, 200, seed=91, sigma=8.0)
+    st, want = T.oracle_decode(data)
+    assert st == T.DECODE_DONE
+    p = T.oracle_parse(data)
+    got, bands = ctx.decode_scan_banded(T.make_frame(p), p.scan, band_rows)
+    assert np.array_equal(got, want)
+    step = band_rows if band_rows else 200
+    step = min(step, 200)
+    assert bands == [(r, min(step, 200 - r)) for r in range(0, 200, step)]
