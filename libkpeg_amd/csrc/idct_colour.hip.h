@@ -569,11 +569,15 @@ __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, 
     return level_shift((float)(0.25 * (double)sum));
 }
 
-#ifndef KPEG_K4_MAX3
-#define KPEG_K4_MAX3 0
+#ifndef KPEG_PUSH_GROUP
+#define KPEG_PUSH_GROUP 4           // pixel columns per unsafe-pixel test, dense layout (measured 1 / 2 / 4: 68.9 / 65.3 / 64.0 us)
+#endif
+#ifndef KPEG_PUSH_GROUP_COMPACT
+#define KPEG_PUSH_GROUP_COMPACT 2   // ... compact stream (69.0 / 68.1 / 71.3 us: four keep too many registers live there)
 #endif
 #ifndef KPEG_K4_STASH_DENSE
-#define KPEG_K4_STASH_DENSE 1   // dense layout: queue entries carry their blocks' corner words too (0: the fix-up pass loads them)
+#define KPEG_K4_STASH_DENSE 0   // dense layout: 1 = queue entries carry their blocks' corner words too (six lane shuffles per tile and six
+                                // more VGPRs: measured no gain); 0 = the fix-up pass loads them from the coefficient buffer
 #endif
 #ifndef KPEG_K4_CHROMA2
 #define KPEG_K4_CHROMA2 0
@@ -1033,15 +1037,27 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             in.dcw = l < 24u ? (uint32_t)(uint16_t)p.dc16[mcu_ld * 3 + l] : 0u;
         } else {
             const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu_ld * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
+#if defined(KPEG_ABLATE_HALFLINE)
+            // timing experiment: rows 4..7 (the second 64 bytes of every block) are not loaded -- does half a line cost half?
+            in.d0 = in.d1 = in.d2 = make_uint4(0, 0, 0, 0);
+            if (u < 4) in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+#elif defined(KPEG_ABLATE_QUARTERLINE)
+            in.d0 = in.d1 = in.d2 = make_uint4(0, 0, 0, 0);
+            if (u < 2) in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+#else
             in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+#endif
         }
         const float* eb = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(p.ebound + mcu_ld * 3) + lane_mcu * 12u);
         in.e0 = eb[0], in.e1 = eb[1], in.e2 = eb[2];
     };
+    // The dense layout's inputs (12 VGPRs of rows) are NOT asked for ahead: measured no gain (the kernel is bound by HBM
+    // bytes and by its own instruction stream, not by that round trip), and the registers are needed elsewhere.
+    constexpr bool PREFETCH = COMPACT;
     uint32_t tilek_cur = take_tile(), tilek_next = take_tile();
     TileIn cur, nxt;
     uint32_t rs_next = 0, rn_next = 0, rs_after = 0, rn_after = 0;
-    if (tilek_cur < wg_ntiles) {
+    if (PREFETCH && tilek_cur < wg_ntiles) {
         uint32_t rs = 0, rn = 0;
         if constexpr (COMPACT) tile_records(tilek_cur, rs, rn);
         issue_loads(tilek_cur, cur, rs, rn);
@@ -1057,8 +1073,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         tilek_after = take_tile();
         if constexpr (COMPACT)
             if (tilek_after < wg_ntiles) tile_records(tilek_after, rs_after, rn_after);   // two tiles ahead: nothing waits for these
-        if (tilek_next < wg_ntiles) issue_loads(tilek_next, nxt, rs_next, rn_next);   // the next tile's inputs travel while this one is computed
-        asm volatile("" ::: "memory");
+        if constexpr (!PREFETCH) issue_loads(tilek, cur, 0, 0);
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;                       // first MCU column of the tile
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);  // MCUs in this tile
@@ -1089,13 +1104,19 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             d0 = cur.d0, d1 = cur.d1, d2 = cur.d2;
         }
         const float e0 = cur.e0, e1 = cur.e1, e2 = cur.e2;
+        if constexpr (PREFETCH) {
+            // the next tile's inputs travel while this one is computed (asked for here, behind the rebuild: this tile's
+            // records are dead by now and their registers free)
+            if (tilek_next < wg_ntiles) issue_loads(tilek_next, nxt, rs_next, rn_next);
+            asm volatile("" ::: "memory");
+        }
         // The first word of rows 0 and 1 of the MCU's three blocks (coefficients (0,0),(0,1) and (1,0),(1,1)): they sit on
         // lanes 0 and 4 of the group.  A queued pixel takes them along, so the fix-up pass settles corner-only blocks (nine
         // unsafe samples in ten) without touching memory.
         constexpr bool STASH = COMPACT || KPEG_K4_STASH_DENSE;
         const int lrow0 = tid & 56, lrow1 = lrow0 | 4;
         uint32_t cw00 = 0, cw01 = 0, cw10 = 0, cw11 = 0, cw20 = 0, cw21 = 0;
-        if constexpr (STASH) {
+        if constexpr (STASH && !COMPACT) {   // (the compact path reads them from the tile's LDS image when it queues a pixel)
             cw00 = (uint32_t)__shfl((int)d0.x, lrow0), cw01 = (uint32_t)__shfl((int)d0.x, lrow1);
             cw10 = (uint32_t)__shfl((int)d1.x, lrow0), cw11 = (uint32_t)__shfl((int)d1.x, lrow1);
             cw20 = (uint32_t)__shfl((int)d2.x, lrow0), cw21 = (uint32_t)__shfl((int)d2.x, lrow1);
@@ -1143,11 +1164,6 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
 #endif
         // |fast - rint(fast)| + nthr >= 0  <=>  within the block's bound of a rounding boundary
         const float nthr0 = fabsf(e0) - 0.5f, nthr1 = fabsf(e1) - 0.5f, nthr2 = fabsf(e2) - 0.5f;
-#if KPEG_K4_MAX3
-        // one test for the three samples of a pixel: the largest of the three distances against the largest of the three
-        // bounds (conservative; v_max3_f32 + one add instead of three adds and two ands per pixel)
-        const float nthr_max = fmaxf(fmaxf(fabsf(e0), fabsf(e1)), fabsf(e2)) - 0.5f;
-#endif
         // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
         const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
         const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
@@ -1164,6 +1180,9 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                                   ((__float_as_uint(e1) >> 31) << 10) | ((__float_as_uint(e2) >> 31) << 11);
         const unsigned long long active_mask = __ballot(active);
         bool pushed_nc = false;   // compact stream: this tile queued a pixel with an unsafe sample in a block that is not corner-only
+        uint32_t nc_lane = 0;
+        constexpr int PG = COMPACT ? KPEG_PUSH_GROUP_COMPACT : KPEG_PUSH_GROUP;   // pixel columns per unsafe-pixel test
+        uint32_t gsafe = 0x80000000u, sf[PG];
         // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
         auto pixel_loop = [&](auto with_wide) {
 #pragma unroll
@@ -1171,12 +1190,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                 const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
                 const float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
                 // >= 0: the fast value is within its block's bound of a rounding boundary
-#if KPEG_K4_MAX3
-                const float dy = vy - ry, db = vb - rb, dr = vr - rr;
-                const float fall = fmaxf(fmaxf(fabsf(dy), fabsf(db)), fabsf(dr)) + nthr_max;
-#else
                 const float fy = fabsf(vy - ry) + nthr0, fb = fabsf(vb - rb) + nthr1, fr = fabsf(vr - rr) + nthr2;
-#endif
                 // colour from the three rounded samples (minus the level shift); dt = how far the G term's t is from
                 // an integer, as seen by the f32 arithmetic
                 // v_cvt_pk_u8_f32 rounds to nearest-even and saturates.  All three channels are handed to it 0.499 below
@@ -1208,48 +1222,65 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                         kg = 0x80000000u;   // G is exact here
                     }
                 }
-#if KPEG_K4_MAX3
-                const uint32_t safe = __float_as_uint(fall) & kg;
-#else
                 const uint32_t safe = __float_as_uint(fy) & __float_as_uint(fb) & __float_as_uint(fr) & kg;
-#endif
                 pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
                 pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
                 pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
-#ifndef KPEG_ABLATE_PUSH
-                // one wave-uniform test per pixel column: nobody flagged -> next column
-                const unsigned long long bal = __ballot((int)safe >= 0) & active_mask;
-                if (bal) {
-                    const uint32_t slot = nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-                    if ((int)safe >= 0 && active) {
-                        const uint32_t pw = pos_lane | ((uint32_t)i << 6);
-                        if (slot < QUEUE_CAP) {
-                            uint32_t* q = s_queue + slot * QW;
-                            q[0] = pw;
-#ifndef KPEG_PUSH_POS_ONLY
-                            q[1] = __float_as_uint(ry), q[2] = __float_as_uint(rb), q[3] = __float_as_uint(rr);
-#if KPEG_K4_MAX3
-                            // per component, with its own bound (a pixel flagged by the common test may need nothing)
-                            q[4] = __float_as_uint(fabsf(dy) + nthr0), q[5] = __float_as_uint(fabsf(db) + nthr1), q[6] = __float_as_uint(fabsf(dr) + nthr2);
-#else
-                            q[4] = __float_as_uint(fy), q[5] = __float_as_uint(fb), q[6] = __float_as_uint(fr);
+#if defined(KPEG_ABLATE_PUSH_KEEPSAFE)
+                // timing experiment: the safety arithmetic stays (kept alive), no test, no queue
+                asm volatile("" ::"v"(safe));
+#elif !defined(KPEG_ABLATE_PUSH)
+                // A scalar branch on a vector compare costs a wavefront ~175 cycles (the VALU result has to reach the scalar
+                // unit): one test per pixel column -- eight per tile, plus one more in every taken branch -- was 13 us of the
+                // kernel (profiles/r02: ablations).  So: one test per GROUP of KPEG_PUSH_GROUP columns; a group with an unsafe
+                // pixel (2.5 pixels per tile on the 8K workload) takes its ballots together and queues its pixels with
+                // ballot compaction (no atomics).
+                sf[i % PG] = safe;
+                gsafe &= safe;
+                if ((i % PG) == PG - 1) {
+                    if (__ballot((int)gsafe >= 0) & active_mask) {
+                        unsigned long long gb[PG];
+#pragma unroll
+                        for (int j = 0; j < PG; ++j) gb[j] = __ballot((int)sf[j] >= 0) & active_mask;
+                        uint32_t base_slot = nq;
+#pragma unroll
+                        for (int j = 0; j < PG; ++j) {
+                            const int ii = i - (PG - 1) + j;
+                            const unsigned long long bal = gb[j];
+                            const uint32_t slot = base_slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+#ifdef KPEG_ABLATE_PUSHBODY
+                            if (slot == 0xFFFFFFFFu)   // timing experiment: the tests and the count stay, the entry is never written
 #endif
-#endif
-                            // the 2x2 corner of the pixel's three blocks (rows 0 and 1, columns 0 and 1)
-                            if constexpr (STASH) q[8] = cw00, q[9] = cw01, q[10] = cw10, q[11] = cw11, q[12] = cw20, q[13] = cw21;
-                        } else {
-                            s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
+                            if ((int)sf[j] >= 0 && active) {
+                                // the pixel's rounded samples and keys again, from the fast values (cheaper than keeping them)
+                                const float wy = v[0][ii], wb = v[1][ii], wr = v[2][ii];
+                                const float qy = __builtin_rintf(wy), qb = __builtin_rintf(wb), qr = __builtin_rintf(wr);
+                                const float gy = fabsf(wy - qy) + nthr0, gbk = fabsf(wb - qb) + nthr1, gr = fabsf(wr - qr) + nthr2;
+                                const uint32_t pw = pos_lane | ((uint32_t)ii << 6);
+                                if (slot < QUEUE_CAP) {
+                                    uint32_t* q = s_queue + slot * QW;
+                                    q[0] = pw;
+                                    q[1] = __float_as_uint(qy), q[2] = __float_as_uint(qb), q[3] = __float_as_uint(qr);
+                                    q[4] = __float_as_uint(gy), q[5] = __float_as_uint(gbk), q[6] = __float_as_uint(gr);
+                                    // the 2x2 corner of the pixel's three blocks (rows 0 and 1, columns 0 and 1)
+                                    if constexpr (COMPACT) {
+                                        const uint32_t* im = s_img + (grp * 3) * 32;   // block c at + 32 c words: rows 0 and 1 at words 0 and 4
+                                        q[8] = im[0], q[9] = im[4], q[10] = im[32], q[11] = im[36], q[12] = im[64], q[13] = im[68];
+                                    } else if constexpr (STASH) {
+                                        q[8] = cw00, q[9] = cw01, q[10] = cw10, q[11] = cw11, q[12] = cw20, q[13] = cw21;
+                                    }
+                                } else {
+                                    s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
+                                }
+                                if constexpr (COMPACT)
+                                    nc_lane |= (~__float_as_uint(gy) & ~__float_as_uint(e0)) | (~__float_as_uint(gbk) & ~__float_as_uint(e1)) |
+                                               (~__float_as_uint(gr) & ~__float_as_uint(e2));   // sign set: unsafe (key >= 0) in a block whose bound is positive (not corner-only)
+                            }
+                            base_slot += __popcll(bal);
                         }
+                        nq = base_slot;
                     }
-                    nq += __popcll(bal);
-                    if constexpr (COMPACT) {
-#if KPEG_K4_MAX3
-                        const float fy = fabsf(dy) + nthr0, fb = fabsf(db) + nthr1, fr = fabsf(dr) + nthr2;
-#endif
-                        const uint32_t ncb = (~__float_as_uint(fy) & ~__float_as_uint(e0)) | (~__float_as_uint(fb) & ~__float_as_uint(e1)) |
-                                             (~__float_as_uint(fr) & ~__float_as_uint(e2));   // sign set: unsafe (key >= 0) in a block whose bound is positive (not corner-only)
-                        pushed_nc = pushed_nc || __ballot((int)ncb < 0 && (int)safe >= 0 && active) != 0;
-                    }
+                    gsafe = 0x80000000u;
                 }
 #else
                 (void)safe;
@@ -1258,7 +1289,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         };
         if (any_wide) pixel_loop(std::true_type{});
         else pixel_loop(std::false_type{});
-
+        if constexpr (COMPACT) pushed_nc = __ballot((int)nc_lane < 0) != 0;
         {
             // 24 bytes of pixel row lane8, MCU grp (groups beyond nm write garbage that is never stored)
             uint2* dst = reinterpret_cast<uint2*>(s_tile + lane8 * TILE_ROW_STRIDE + grp * 24);
@@ -1274,7 +1305,9 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         if constexpr (COMPACT) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#ifndef KPEG_ABLATE_RESOLVE
             if (pushed_nc) resolve_noncorner(min(nq_tile, (uint32_t)QUEUE_CAP), nq);   // while this tile's image stands
+#endif
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1291,7 +1324,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             nover = 0;
         }
         if (!more) break;
-        cur = nxt;
+        if constexpr (PREFETCH) cur = nxt;
         tilek_cur = tilek_next;
         tilek_next = tilek_after;
         rs_next = rs_after, rn_next = rn_after;

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--width", type=int, default=bench.W8K)
     ap.add_argument("--height", type=int, default=bench.H8K)
+    ap.add_argument("--idct-mode", type=int, default=0, help="kpeg_hip_set_idct_mode: 2 = unsafe pixels are queued but not re-evaluated (wrong pixels: what the queueing alone costs)")
     args = ap.parse_args()
     import torch
     import libkpeg_amd as K
@@ -58,6 +59,7 @@ def main():
     for name, lib in libs.items():
         c = K.Context(0, lib=lib)
         c.set_stream(stream)
+        c.set_idct_mode(args.idct_mode)
         ctxs[name] = c
     first = next(iter(ctxs.values()))
     first.entropy_decode_dev(frame, d_scan.data_ptr(), d_scan.numel(), d_coef.data_ptr())
