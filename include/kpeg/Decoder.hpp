@@ -58,6 +58,9 @@ namespace kpeg
             // ---- additions (off by default, outside the parity contract) ----
             /// Accept DRI / RSTn (the reference rejects them).
             void setRestartMarkerSupport( bool on ) { allowDRI_ = on; }
+            /// Extension, off by default: accept one-component (grayscale) baseline files.  The reference reads three
+            /// component triples whatever SOF0's count says (src/Decoder.cpp:339) and fails on them.
+            void setGrayscaleSupport( bool on ) { allowGray_ = on; }
             /// Parse only: stop at the seam and leave the tables for frameInfo().
             void setParseOnly( bool on ) { parseOnly_ = on; }
             /// Tables and geometry as handed to the GPU path; valid after decodeImageFile().
@@ -104,6 +107,8 @@ namespace kpeg
             int sosCount_;
             UInt32 restartInterval_;
             bool allowDRI_, parseOnly_;
+            bool allowGray_ = false;
+            int components_ = 3;
     };
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KPEG_HIP_ABI_VERSION 1
+#define KPEG_HIP_ABI_VERSION 2
 
 enum {
     KPEG_HIP_OK = 0,
@@ -61,6 +61,10 @@ typedef struct kpeg_frame {
                                    id 1 -> Cb, Cr (hard-wired, Decoder.cpp:704)               */
     uint32_t restart_interval;  /* MCUs per restart interval; 0 = a stream the reference
                                    accepts (it rejects DRI)                    */
+    uint32_t components;        /* 0 or 3 = Y Cb Cr 4:4:4, what the reference decodes; 1 = grayscale (extension, off by
+                                   default in the host parser: the reference reads three component triples whatever
+                                   SOF0 says, src/Decoder.cpp:339, and fails on such files): one block per MCU decoded with
+                                   table id 0 through the same per-block arithmetic, R = G = B = clamp(Y)                */
 } kpeg_frame;
 
 /* Per-call device timings (milliseconds, HIP events on the context's stream), valid after

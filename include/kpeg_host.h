@@ -18,6 +18,7 @@ extern "C" {
 #endif
 
 #define KPEG_PARSE_ALLOW_DRI 1u /* extension: accept DRI/RSTn (the reference rejects them) */
+#define KPEG_PARSE_ALLOW_GRAY 2u /* extension: accept one-component (grayscale) baseline files (the reference fails on them) */
 
 /* Returns the reference's JPEGDecoder::ResultCode (0 SUCCESS, 1 TERMINATE, 2 ERROR,
  * 3 DECODE_INCOMPLETE, 4 DECODE_DONE), or -1 when the tables are outside the supported

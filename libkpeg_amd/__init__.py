@@ -16,7 +16,7 @@ HIP_LIB = os.environ.get("KPEG_HIP_LIB") or os.path.join(_HERE, "libkpeg_hip.so"
 HOST_LIB = os.path.join(_HERE, "libkpeg.so")
 CLI = os.path.join(_HERE, "kpeg")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 E_ARG, E_DEVICE, E_TABLES, E_STREAM, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
@@ -39,6 +39,7 @@ class Frame(ctypes.Structure):
         ("qt", (ctypes.c_uint16 * 64) * 2),
         ("dht", (Dht * 2) * 2),
         ("restart_interval", ctypes.c_uint32),
+        ("components", ctypes.c_uint32),
     ]
 
 
@@ -262,6 +263,7 @@ def decode_sharded(ctxs, frame, scan, d_rgb_root=None):
 # ---------------------------------------------------------------------------------------------
 # C++ host library (kpeg::JPEGDecoder marker parser) through its C shim, include/kpeg_host.h
 PARSE_ALLOW_DRI = 1
+PARSE_ALLOW_GRAY = 2
 SUCCESS, TERMINATE, ERROR, DECODE_INCOMPLETE, DECODE_DONE = 0, 1, 2, 3, 4
 _host = None
 
@@ -283,7 +285,7 @@ def load_host():
     return H
 
 
-def host_parse(data, allow_dri=False):
+def host_parse(data, allow_dri=False, allow_gray=False):
     """Run the product's marker parser on an in-memory JFIF file.
     Returns (result_code, Frame or None, scan bytes (numpy uint8) or None)."""
     H = load_host()
@@ -291,7 +293,7 @@ def host_parse(data, allow_dri=False):
     frame = Frame()
     scan = np.empty(buf.size + 1, np.uint8)
     n = ctypes.c_size_t(0)
-    rc = H.kpeg_host_parse(buf.ctypes.data, buf.size, PARSE_ALLOW_DRI if allow_dri else 0, ctypes.byref(frame),
+    rc = H.kpeg_host_parse(buf.ctypes.data, buf.size, (PARSE_ALLOW_DRI if allow_dri else 0) | (PARSE_ALLOW_GRAY if allow_gray else 0), ctypes.byref(frame),
                            scan.ctypes.data, scan.size, ctypes.byref(n))
     if rc != DECODE_DONE:
         return rc, None, None

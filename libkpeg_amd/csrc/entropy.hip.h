@@ -274,6 +274,7 @@ struct EntropyLaunch {
     uint32_t ntiles = 0;
     unsigned long long spin_ticks = 0;   // bound of the waits between workgroups in 100 MHz ticks, 0 = defaults (test hook)
     uint32_t fault = 0;                  // fault injection (test hook): bit 0 K0's, bit 1 K1's workgroup 0 never publishes
+    uint32_t gray = 0;                   // one-component stream (kpeg_frame::components == 1)
     // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
     // from the known state, DC predictors reset): d_scan / scan_len are unused, restart_interval = MCUs per image
     uint32_t nimg = 0;
@@ -786,9 +787,11 @@ struct RunResult {
 
 // Sync/count run: decode from `s` until the bit position reaches `pend`.  COUNT: also count the records of the compact
 // coefficient stream (left out where the dense layout is written: K1 is the pipeline's longest kernel).
+// gray (wave-uniform): one component -- the table sequence is DC0 AC0 and every block adds to the one DC sum.
 template <bool COUNT>
-__device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend)
+__device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend, bool gray)
 {
+    const uint32_t tb_wrap = gray ? 2 * LUT_BYTES : 6 * LUT_BYTES;
     BitReader br;
     br.init(bits, w0, s.p);
     uint32_t p = s.p, k = s.k, q = s.q, tb = state_table(s);
@@ -811,15 +814,15 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
         k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
         q = adv ? ((e >> 25) & 1u) : q;
         tb += adv ? LUT_BYTES : 0u;
-        tb = tb == 6 * LUT_BYTES ? 0u : tb;
+        tb = tb == tb_wrap ? 0u : tb;
         p += e & 31;
         br.consume(e & 31);
         e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way (one read too many at the end: harmless)
         if (e & E_ISDC) {
             const int n = s0 + extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
-            s0 = s1;
-            s1 = s2;
-            s2 = n;
+            s0 = gray ? n : s1;
+            s1 = gray ? s1 : s2;
+            s2 = gray ? s2 : n;
             nb++;
         }
 #if KPEG_SYNC_STATS
@@ -828,7 +831,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
     }
     RunResult r;
     // slot j holds component (cfirst + nb + j) mod 3
-    const uint32_t rot = (cfirst + nb) % 3;
+    const uint32_t rot = gray ? 0u : (cfirst + nb) % 3;
     r.nrec = nrec;
     r.cnt.x = (int)nb;
     r.cnt.y = rot == 0 ? s0 : (rot == 1 ? s2 : s1);
@@ -911,6 +914,7 @@ struct SyncArgs {
     uint32_t* status;   // [1]: error flags (a chained wait that timed out); KPEG_SYNC_STATS builds: words 8..13 collect loop counts
     unsigned long long spin_ticks;   // bound of the chained pass's wait for the predecessor (SpinGuard)
     uint32_t fault;     // test hook: bit 1 = workgroup 0 of a rippling chained pass never publishes
+    uint32_t gray;      // one-component stream (extension): see run_count; the chroma blocks' bounds are preset to "exact"
 };
 constexpr uint64_t X_NONE = ~0ull;
 
@@ -1130,7 +1134,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 s.c = 0;
                 s.k = 0;
                 s.q = 0;
-                const RunResult r = run_count<COUNT>(T, s_bits, w0, s, geo.pend);
+                const RunResult r = run_count<COUNT>(T, s_bits, w0, s, geo.pend, a.gray != 0);
 #if KPEG_SYNC_STATS
                 st_runs++;
                 st_iters += r.iters;
@@ -1181,7 +1185,8 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         }
         const uint32_t eper = (a.nblocks + nwg - 1) / nwg;
         const uint32_t e0 = min(a.nblocks, g * eper), e1 = min(a.nblocks, e0 + eper);
-        for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = 0x7F800000u;
+        // (grayscale: the MCU's chroma blocks stay all zero -- bound -0.0 = exact and corner-only; only luma is decoded)
+        for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = (a.gray && q % 3u) ? 0x80000000u : 0x7F800000u;
         if (t == 0) {
             a.bslot[g] = 0ull;
             a.done[g] = 0u;
@@ -1209,7 +1214,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
                 // exit state yet: either value is a valid start, and if it moved this item is on
                 // the next list again
                 const uint64_t before = s_X[j + 1];   // (read with the entry state: one LDS round trip, not two)
-                const RunResult r = run_count<COUNT>(T, s_bits, w0, unpack_state(s_X[j]), s_geo[j] & 0x7FFFFFFFu);
+                const RunResult r = run_count<COUNT>(T, s_bits, w0, unpack_state(s_X[j]), s_geo[j] & 0x7FFFFFFFu, a.gray != 0);
 #if KPEG_SYNC_STATS
                 st_runs++;
                 st_iters += r.iters;
@@ -1325,6 +1330,7 @@ struct WriteArgs {
     int16_t* dc16;           // [blocks]
     uint32_t* tile_start;    // [ntiles + 1], preset to 0 by K1
     uint32_t ntiles;
+    uint32_t gray;           // one-component stream (extension, dense layout only): every block is block 0 of its MCU
 };
 constexpr uint32_t TILE_BLOCKS = 24;   // K4's tile: 8 MCUs x 3 components
 
@@ -1450,15 +1456,18 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         }
         const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
         const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
-        const uint32_t blk_limit = seg_mcus * 3;       // blocks of this segment
+        const bool gray = a.gray != 0;                 // one block per MCU, stored as the MCU's luma block (stride 3)
+        const uint32_t bstride = gray ? 3u : 1u;
+        const uint32_t blk_limit = gray ? seg_mcus : seg_mcus * 3;   // blocks of this segment
         uint32_t b = (uint32_t)pre.x;                  // blocks started so far, within the segment
 
         BitReader br;
         br.init(s_bits, w0, s.p);
         uint32_t p = s.p, k = s.k, tb = state_table(s);
+        const uint32_t tb_wrap = gray ? 2 * LUT_BYTES : 6 * LUT_BYTES;
         // DC predictors rotate with the blocks: pd0 belongs to the next block to start (component b % 3,
         // == the component of the table in use on a valid stream); DCDiff[c] += zz[0] (MCU.cpp:107)
-        const uint32_t cb = b % 3;
+        const uint32_t cb = gray ? 0u : b % 3;
         int pd0 = cb == 0 ? pre.y : (cb == 1 ? pre.z : pre.w);
         int pd1 = cb == 0 ? pre.z : (cb == 1 ? pre.w : pre.y);
         int pd2 = cb == 0 ? pre.w : (cb == 1 ? pre.y : pre.z);
@@ -1487,7 +1496,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
         int nnz = 0;
         const uint32_t gbase = seg_mcu0 * 3;
-        uint32_t gb = gbase + (b ? b - 1 : 0);          // block in progress
+        uint32_t gb = gbase + (b ? b - 1 : 0) * bstride;          // block in progress
         if (k != 0 && b == 0) err |= 64;                // inside a block before the segment's first one began
         // a corrupt stream can count more blocks than the segment has: nothing is written for those
         constexpr uint32_t F_INSIDE = 1u << 11;         // the block in progress lies inside the segment
@@ -1507,7 +1516,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             const uint32_t tdc = tb >= 2 * LUT_BYTES ? 1u : 0u;   // chroma tables
             k = adv ? ((e >> 14) & 1u) : kraw;
             tb += adv ? LUT_BYTES : 0u;
-            tb = tb == 6 * LUT_BYTES ? 0u : tb;
+            tb = tb == tb_wrap ? 0u : tb;
             e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way
             const int ext = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
             ebits |= e;
@@ -1515,10 +1524,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             const int n = pd0 + ext;
             if (isdc) {
                 dcrange |= (uint32_t)(n + 32768);   // bits above 15: the absolute DC does not fit the int16 coefficient layout
-                pd0 = pd1;
-                pd1 = pd2;
-                pd2 = n;
-                gb = gbase + b;
+                pd0 = gray ? n : pd1;
+                pd1 = gray ? pd1 : pd2;
+                pd2 = gray ? pd2 : n;
+                gb = gbase + b * bstride;
                 b++;
                 if (COMPACT) {
                     bm_cur = bmn;
@@ -1778,6 +1787,7 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.status = L.d_status;
     sa.spin_ticks = L.spin_ticks ? L.spin_ticks : K1_SPIN_TICKS;
     sa.fault = L.fault;
+    sa.gray = L.gray;
     const int npass = L.sync_passes >= 3 ? L.sync_passes : SYNC_PASSES;   // the last one is chained and runs the scan
     sa.part = (unsigned long long*)S->d_part;
     sa.nparts = nparts;
@@ -1814,6 +1824,7 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     wa.dc16 = L.d_dc16;
     wa.tile_start = L.d_tile_start;
     wa.ntiles = L.ntiles;
+    wa.gray = L.gray;
     if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else hipLaunchKernelGGL((k_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);

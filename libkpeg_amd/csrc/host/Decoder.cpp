@@ -261,9 +261,11 @@ namespace kpeg
         readByte( b );  // precision
         const UInt16 h = readBE16();
         const UInt16 w = readBE16();
-        readByte( b );  // component count (the loop below always reads three triples)
+        readByte( b );  // component count (the reference's loop always reads three triples)
+        // extension: a one-component frame is read as what it is (and decoded as grayscale)
+        components_ = ( allowGray_ && b == 1 ) ? 1 : 3;
         bool nonSampled = true;
-        for ( int i = 0; i < 3; ++i )
+        for ( int i = 0; i < components_; ++i )
         {
             readByte( id );
             readByte( samp );
@@ -370,21 +372,23 @@ namespace kpeg
     // ---- the seam ------------------------------------------------------------------------------
     bool JPEGDecoder::frameInfo( kpeg_frame* f ) const
     {
-        if ( !f || tableBroken_ || QTables_.size() < 2 || QTables_[0].size() < 64 || QTables_[1].size() < 64 )
+        const bool gray = components_ == 1;   // one quantiser and one pair of Huffman tables: id 0 stands in for id 1
+        if ( !f || tableBroken_ || QTables_.size() < ( gray ? 1u : 2u ) || QTables_[0].size() < 64 || ( !gray && QTables_[1].size() < 64 ) )
             return false;
         std::memset( f, 0, sizeof( *f ) );
         f->width = image_.getWidth();
         f->height = image_.getHeight();
+        f->components = gray ? 1 : 0;
         for ( int t = 0; t < 2; ++t )
             for ( int k = 0; k < 64; ++k )
-                f->qt[t][k] = QTables_[t][k];  // first 64 entries: what MCU.cpp:110-112 reads
+                f->qt[t][k] = QTables_[gray ? 0 : t][k];  // first 64 entries: what MCU.cpp:110-112 reads
         for ( int cls = 0; cls < 2; ++cls )
             for ( int id = 0; id < 2; ++id )
             {
                 int k = 0;
                 for ( int i = 0; i < 16; ++i )
                 {
-                    const auto& e = huffmanTable_[cls][id][i];
+                    const auto& e = huffmanTable_[cls][gray ? 0 : id][i];
                     if ( e.first < 0 || e.first > 255 || (int)e.second.size() != e.first || k + e.first > 256 )
                         return false;
                     f->dht[cls][id].counts[i] = (UInt8)e.first;

@@ -30,6 +30,7 @@ extern "C" int kpeg_host_parse( const uint8_t* file, size_t size, unsigned flags
         kpeg::JPEGDecoder dec;
         dec.setParseOnly( true );
         dec.setRestartMarkerSupport( ( flags & KPEG_PARSE_ALLOW_DRI ) != 0 );
+        dec.setGrayscaleSupport( ( flags & KPEG_PARSE_ALLOW_GRAY ) != 0 );
         dec.openMemory( file, size, "memory.jpg" );
         const int rc = (int)dec.decodeImageFile();
         if ( rc != (int)kpeg::JPEGDecoder::DECODE_DONE )
@@ -56,6 +57,7 @@ extern "C" int kpeg_host_decode_file( const char* path, unsigned flags )
     {
         kpeg::JPEGDecoder dec;
         dec.setRestartMarkerSupport( ( flags & KPEG_PARSE_ALLOW_DRI ) != 0 );
+        dec.setGrayscaleSupport( ( flags & KPEG_PARSE_ALLOW_GRAY ) != 0 );
         if ( !dec.open( path ) )
             return (int)kpeg::JPEGDecoder::ERROR;
         const int rc = (int)dec.decodeImageFile();

@@ -362,6 +362,10 @@ static int check_frame(kpeg_hip_ctx* ctx, const kpeg_frame* f)
         ctx->last_error = "width/height must be non-zero multiples of 8 (SURVEY.md A.1)";
         return KPEG_HIP_E_ARG;
     }
+    if (f->components != 0 && f->components != 1 && f->components != 3) {
+        ctx->last_error = "components must be 0 / 3 (Y Cb Cr 4:4:4) or 1 (grayscale)";
+        return KPEG_HIP_E_UNSUPPORTED;
+    }
     return KPEG_HIP_OK;
 }
 
@@ -495,7 +499,7 @@ extern "C" int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
 // tiles (width a multiple of 64), and never for the reference-order cross-check kernel, which reads dense blocks.
 static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t scan_bytes, uint64_t nmcu)
 {
-    if (ctx->coef_layout == 1 || ctx->idct_mode == 1) return false;
+    if (ctx->coef_layout == 1 || ctx->idct_mode == 1 || f->components == 1) return false;
     if ((f->width / 8) % TILE_MCUS != 0) return false;
     const bool dense = ctx->subseq ? ctx->subseq >= SUBSEQ_DENSE : scan_bytes * 8 >= nmcu * 64 * 4;   // entropy_decode_launch's rule
     if (ctx->coef_layout == 2) return true;
@@ -528,6 +532,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.sync_passes = ctx->sync_passes;
     L.warm = ctx->warm;
     L.subseq = ctx->subseq;
+    L.gray = f->components == 1 ? 1u : 0u;
     if (compact) {
         // a record takes at least two bits of the stream (a one-bit code and a one-bit magnitude), a block holds at most 63
         const uint64_t bytes = batch ? batch->total_len : (uint64_t)scan_len;

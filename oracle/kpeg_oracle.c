@@ -668,3 +668,138 @@ size_t kpeg_oracle_ppm_header(uint32_t width, uint32_t height, char* buf, size_t
                      width, height);
     return k < 0 ? 0 : (size_t)k;
 }
+
+/* ------------------------------------------------------------------ */
+/* Extension: one-component (grayscale) baseline files                  */
+/* ------------------------------------------------------------------ */
+/* The reference cannot decode these: parseSOF0Segment reads three component triples whatever the
+ * frame header says (Decoder.cpp:339) and runs into the next marker.  PARITY UNPINNED: what is
+ * restated here is the reference's own per-block path -- decodeScanData's symbol loop with its
+ * quirk Q1 (Decoder.cpp:694-803, MCU.cpp:97-108), dequantisation, computeIDCT, performLevelShift
+ * (MCU.cpp:110-245) -- applied to the one component with table id 0, and convertYCbCrToRGB
+ * (MCU.cpp:247-279) on Cb = Cr = 128, i.e. R = G = B = clamp(Y).  The marker walk is the
+ * standard one (segments skipped by their length).  Checked against Pillow's decoder within the
+ * tolerance two different IDCTs allow (tests/test_oracle.py), not against the reference. */
+int kpeg_oracle_decode_gray(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads)
+{
+    kpeg_oracle_jfif j;
+    memset(&j, 0, sizeof(j));
+    size_t pos = 2;
+    if (n < 4 || file[0] != 0xFF || file[1] != 0xD8) return KPEG_ORACLE_ERROR;
+    int have_sof = 0, have_q = 0;
+    uint32_t ri = 0;
+    while (pos + 4 <= n) {
+        if (file[pos] != 0xFF) return KPEG_ORACLE_ERROR;
+        const uint8_t m = file[pos + 1];
+        const size_t len = ((size_t)file[pos + 2] << 8) | file[pos + 3];
+        if (len < 2 || pos + 2 + len > n) return KPEG_ORACLE_ERROR;
+        const uint8_t* p = file + pos + 4;
+        const size_t body = len - 2;
+        if (m == 0xDB) {
+            for (size_t o = 0; o + 65 <= body; o += 65)
+                if ((p[o] & 0x0F) == 0 && (p[o] >> 4) == 0) {
+                    for (int i = 0; i < 64; ++i) j.qt[0][i] = j.qt[1][i] = p[o + 1 + i];
+                    have_q = 1;
+                }
+        } else if (m == 0xC0) {
+            if (body < 9 || p[0] != 8 || p[5] != 1 || p[7] != 0x11) return KPEG_ORACLE_OUT_OF_CONTRACT;
+            j.height = ((uint32_t)p[1] << 8) | p[2];
+            j.width = ((uint32_t)p[3] << 8) | p[4];
+            have_sof = 1;
+        } else if (m == 0xC4) {
+            size_t o = 0;
+            while (o + 17 <= body) {
+                const int cls = (p[o] >> 4) & 1, id = p[o] & 0x0F;
+                int total = 0;
+                for (int i = 0; i < 16; ++i) total += p[o + 1 + i];
+                if (o + 17 + (size_t)total > body || total > 256) return KPEG_ORACLE_ERROR;
+                if (id == 0)
+                    for (int t = 0; t < 2; ++t) {   /* id 0 stands in for id 1: one component */
+                        kpeg_oracle_dht* d = &j.dht[cls][t];
+                        memset(d, 0, sizeof(*d));
+                        memcpy(d->counts, p + o + 1, 16);
+                        memcpy(d->symbols, p + o + 17, (size_t)total);
+                        d->nsymbols = total;
+                        d->defined = 1;
+                    }
+                o += 17 + (size_t)total;
+            }
+        } else if (m == 0xDD) {
+            if (body >= 2) ri = ((uint32_t)p[0] << 8) | p[1];   /* every interval is decoded as a stream of its own, as for colour (kpeg_oracle_entropy_decode_rst) */
+        } else if (m == 0xDA) {
+            if (body < 1 || p[0] != 1) return KPEG_ORACLE_OUT_OF_CONTRACT;
+            pos += 2 + len;
+            break;
+        } else if (m == 0xC1 || m == 0xC2) {
+            return KPEG_ORACLE_TERMINATE;
+        }
+        pos += 2 + len;
+    }
+    j.nqt = 2;
+    if (!have_sof || !have_q || !have_tables(&j) || j.width == 0 || j.height == 0 || (j.width & 7) || (j.height & 7))
+        return KPEG_ORACLE_OUT_OF_CONTRACT;
+    /* scanImageData's rule (Decoder.cpp:544-574) on the bytes after the SOS header */
+    uint8_t* scan = (uint8_t*)malloc(n - pos + 2);
+    size_t sl = 0;
+    while (pos < n) {
+        uint8_t b = file[pos++];
+        if (b == 0xFF) {
+            const uint8_t nx = pos < n ? file[pos++] : 0xFF;
+            if (nx == 0xD9) break;
+            scan[sl++] = 0xFF;
+            b = nx;
+        }
+        scan[sl++] = b;
+    }
+    const uint32_t nmcu = (j.width * j.height) / 64;
+    int16_t* coef = (int16_t*)calloc((size_t)nmcu * 192, sizeof(int16_t));   /* chroma blocks stay zero: samples 0 + 128 */
+    codebook dc, ac;
+    build_codebook(&j.dht[0][0], &dc);
+    build_codebook(&j.dht[1][0], &ac);
+    uint8_t* tmp = (uint8_t*)malloc(sl + 4);
+    int rc = 0;
+    size_t at = 0;
+    for (uint32_t done = 0; done < nmcu && !rc;) {
+        size_t e = sl, ulen;
+        uint32_t cnt = nmcu - done;
+        if (ri) {
+            for (e = at; e < sl; ++e)
+                if (scan[e] == 0xFF && e + 1 < sl && scan[e + 1] >= 0xD0 && scan[e + 1] <= 0xD7) break;
+            memcpy(tmp, scan + at, e - at);
+            tmp[e - at] = tmp[e - at + 1] = 0;
+            ulen = kpeg_oracle_unstuff(tmp, e - at + 2, tmp);
+            if (cnt > ri) cnt = ri;
+        } else {
+            ulen = kpeg_oracle_unstuff(scan, sl, tmp);
+        }
+        bitrd b = {tmp, (uint64_t)ulen * 8, 0};
+        int pred = 0, zz[64];
+        for (uint32_t m = done; m < done + cnt && !rc; ++m) {
+            if (!decode_block(&b, &dc, &ac, zz)) {
+                rc = KPEG_ORACLE_OUT_OF_CONTRACT;
+                break;
+            }
+            pred += zz[0];
+            zz[0] = pred;
+            for (int k = 0; k < 64; ++k) {
+                if (zz[k] < -32768 || zz[k] > 32767) rc = KPEG_ORACLE_OUT_OF_CONTRACT;
+                coef[(size_t)m * 192 + k] = (int16_t)zz[k];
+            }
+        }
+        done += cnt;
+        at = e + 2;
+    }
+    free(tmp);
+    free(scan);
+    if (rc) {
+        free(coef);
+        return rc;
+    }
+    uint8_t* out = (uint8_t*)malloc((size_t)j.width * j.height * 3);
+    kpeg_oracle_idct_colour(coef, (const uint16_t(*)[64])j.qt, j.width, j.height, out, nthreads);
+    free(coef);
+    *rgb = out;
+    *width = j.width;
+    *height = j.height;
+    return KPEG_ORACLE_DECODE_DONE;
+}

@@ -93,6 +93,10 @@ void kpeg_oracle_idct_colour(const int16_t* coef, const uint16_t qt[2][64], uint
 int kpeg_oracle_decode(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width,
                        uint32_t* height, int nthreads);
 
+/* Extension (parity unpinned: the reference cannot decode such files): a one-component baseline file through the
+ * reference's per-block arithmetic, R = G = B = clamp(Y).  See kpeg_oracle.c. */
+int kpeg_oracle_decode_gray(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads);
+
 /* Header of Image::dumpRawData (Image.cpp:124-127). Returns its length. */
 size_t kpeg_oracle_ppm_header(uint32_t width, uint32_t height, char* buf, size_t cap);
 

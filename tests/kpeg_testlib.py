@@ -183,6 +183,23 @@ def oracle_decode(data, nthreads=8):
     return st, a
 
 
+def oracle_decode_gray(data, nthreads=8):
+    """The one-component extension (oracle/kpeg_oracle.c: parity unpinned, the reference cannot decode these).
+    Returns (status, rgb or None)."""
+    L = oracle()
+    L.kpeg_oracle_decode_gray.restype = ctypes.c_int
+    L.kpeg_oracle_decode_gray.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                          ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_int]
+    rgb = ctypes.POINTER(ctypes.c_uint8)()
+    w, h = ctypes.c_uint32(), ctypes.c_uint32()
+    st = L.kpeg_oracle_decode_gray(data, len(data), ctypes.byref(rgb), ctypes.byref(w), ctypes.byref(h), nthreads)
+    if st != DECODE_DONE:
+        return st, None
+    a = np.ctypeslib.as_array(rgb, shape=(h.value, w.value, 3)).copy()
+    L.free(rgb)
+    return st, a
+
+
 def oracle_decode_rst(data, restart_interval, nthreads=8):
     """Oracle for DRI streams (rejected by the reference): strip the DRI segment for parsing,
     decode every restart interval as its own stream."""

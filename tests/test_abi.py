@@ -39,8 +39,9 @@ def test_frame_struct_layout_matches_header():
     import libkpeg_amd
     # uint32 x2, uint16[2][64], {uint8[16], uint8[256]}[2][2], uint32
     assert ctypes.sizeof(libkpeg_amd.Dht) == 272
-    assert ctypes.sizeof(libkpeg_amd.Frame) == 8 + 256 + 4 * 272 + 4
+    assert ctypes.sizeof(libkpeg_amd.Frame) == 8 + 256 + 4 * 272 + 8
     assert libkpeg_amd.Frame.restart_interval.offset == 8 + 256 + 4 * 272
+    assert libkpeg_amd.Frame.components.offset == 8 + 256 + 4 * 272 + 4
 
 
 def test_no_cpu_fallback_without_gpu():
