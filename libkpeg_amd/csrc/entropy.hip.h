@@ -85,7 +85,10 @@ constexpr int ITEMS = SYNC_WG;
     (void)SUBSEQ_BITS;                                                                                                    \
     (void)SUBSEQ_WORDS
 
-constexpr int LUT_BITS = 9;
+#ifndef KPEG_LUT_BITS
+#define KPEG_LUT_BITS 9
+#endif
+constexpr int LUT_BITS = KPEG_LUT_BITS;
 constexpr int LUT2_BITS = 16 - LUT_BITS;  // remaining bits of a long code
 #ifndef KPEG_POOL_SUBS
 #define KPEG_POOL_SUBS 24
@@ -229,6 +232,11 @@ struct SpinGuard {
         return __builtin_amdgcn_s_memrealtime() - t0 > limit;
     }
 };
+
+#if KPEG_SYNC_STATS
+// experiment builds: per-wavefront timeline of K1's pass 0 and of K2 ([wave][8] each; tools/sync_dbg.py)
+__device__ unsigned long long g_ent_stamp[2][8192 * 16];
+#endif
 
 struct EntropyScratch {
     void* d_u = nullptr;        size_t u_cap = 0;       // un-stuffed words
@@ -788,7 +796,9 @@ struct RunResult {
 // Sync/count run: decode from `s` until the bit position reaches `pend`.  COUNT: also count the records of the compact
 // coefficient stream (left out where the dense layout is written: K1 is the pipeline's longest kernel).
 // gray (wave-uniform): one component -- the table sequence is DC0 AC0 and every block adds to the one DC sum.
-template <bool COUNT>
+// SUMS = false: only the exit state is wanted (the first decode of K1, from a guessed entry state: whatever it counts is
+// thrown away with the guess) -- the DC symbols then cost no more than any other.
+template <bool COUNT, bool SUMS = true>
 __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend, bool gray)
 {
     const uint32_t tb_wrap = gray ? 2 * LUT_BYTES : 6 * LUT_BYTES;
@@ -810,7 +820,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
         const bool adv = kraw >= 64;   // this table's turn ends: DC symbol, EOB, 63rd coefficient (Decoder.cpp:759)
         // exactly K2's condition for storing an AC coefficient, minus its check that the block lies inside the segment
         // (K2 never emits more records than are counted here: the counts fix where every lane's records go)
-        if (COUNT) nrec += ((e >> 26) & 1u) & q & (kraw <= 64 ? 1u : 0u);
+        if (COUNT && SUMS) nrec += ((e >> 26) & 1u) & q & (kraw <= 64 ? 1u : 0u);
         k = adv ? ((e >> 14) & 1u) : kraw;   // after a DC symbol 1, after a block 0
         q = adv ? ((e >> 25) & 1u) : q;
         tb += adv ? LUT_BYTES : 0u;
@@ -818,7 +828,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
         p += e & 31;
         br.consume(e & 31);
         e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way (one read too many at the end: harmless)
-        if (e & E_ISDC) {
+        if (SUMS && (e & E_ISDC)) {
             const int n = s0 + extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
             s0 = gray ? n : s1;
             s1 = gray ? s1 : s2;
@@ -1001,10 +1011,10 @@ __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_
 }
 
 // Items of a workgroup: [0, wu) the last wu sub-sequences of its predecessor (warm-up, pass 0 only),
-// [wu, nit) its own.  s_X[j] is the entry state of item j, i.e. the exit state of item j - 1.
+// [wu, nit) its own, one per thread.  The entry state of item j is the exit state of item j - 1.
 // Pass 0: every item decodes from a guessed boundary (its own first bit, DC of component 0; the
-//   first sub-sequence of a restart segment from its known state), then rounds re-decode exactly the
-//   items whose predecessor's exit state moved, until none moves (work list in LDS).  Item 0's
+//   first sub-sequence of a restart segment from its known state), then every wavefront re-decodes exactly the
+//   items whose predecessor's exit state moved, until none moves.  Item 0's
 //   guess cannot be checked here: the warm-up distance makes it irrelevant for the own items unless
 //   the stream needs more than WARM_BITS to re-synchronise.
 // Pass p >= 1: a workgroup whose assumed entry state differs from its predecessor's real exit
@@ -1014,12 +1024,11 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
 {
     KPEG_GEOMETRY(S);
     __shared__ __attribute__((aligned(16))) LdsTables T;
-    __shared__ uint64_t s_X[ITEMS + 1];
-    __shared__ uint32_t s_geo[ITEMS + 1];   // pend | first-of-its-segment << 31
-    __shared__ int4 s_cnt[SYNC_WG];
-    __shared__ uint32_t s_nrec[SYNC_WG];
-    __shared__ uint16_t s_list[2][ITEMS];
-    __shared__ uint32_t s_n[3];
+    __shared__ int4 s_cnt[SYNC_WG];          // wsum_scan's scratch
+    __shared__ uint64_t s_wexit[SYNC_WG / 64];   // every wavefront's last exit state so far ...
+    __shared__ uint32_t s_wdone[SYNC_WG / 64];   // ... and whether it is final
+    __shared__ uint64_t s_edge[2];           // entry state of the first own item, exit state of the last
+    __shared__ uint32_t s_n[1];
     __shared__ int4 s_red[SYNC_WG / 64];
     __shared__ uint32_t s_redn[SYNC_WG / 64];
     constexpr uint32_t STAGE_CAP = ITEMS * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
@@ -1108,63 +1117,64 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
-    if (t < 3) s_n[t] = 0;
-    if (t == 0 && p == 0) {
-        // item 0 starts from its guess (matters as this workgroup's assumption only without warm-up)
-        DecState s0;
-        s0.p = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase).pstart;
-        s0.c = s0.k = s0.q = 0;
-        s_X[0] = pack_state(s0);
-    }
     __syncthreads();
 
+    // Every wavefront settles its 64 consecutive items on its own: no barrier, no work list.  An item's entry state
+    // is its left neighbour's exit state -- one lane over (DPP shift), for lane 0 the last exit state of the
+    // wavefront before, handed over through LDS -- and an item decodes again whenever that differs from the state it
+    // last decoded from.  A round costs the longest decode among the lanes that take part, not the longest of the
+    // workgroup, and nothing else.  A wavefront is done when the one before it is done and none of its lanes wants
+    // another decode.
+    const uint32_t lane = t & 63, wave = t >> 6;
+    const bool have = t < nit;
+    uint32_t pend = 0;
+    bool segfirst = false;      // opens a restart segment: its entry state is known
+    bool fixed = true;          // never decodes again (segfirst; item 0 of pass 0: nothing to check its guess against)
+    uint64_t used = 0;          // the state this item last decoded from
+    RunResult r;
+    r.exit_state = 0;
+    r.cnt = make_int4(0, 0, 0, 0);
+    r.nrec = 0;
 #if KPEG_SYNC_STATS
-    uint32_t st_runs = 0, st_iters = 0, st_rounds = 0;
+    uint32_t st_runs = 0, st_iters = 0, st_rounds = 0, st_wait = 0;
+    r.iters = 0;
     const uint64_t tm1 = __builtin_amdgcn_s_memtime();
 #endif
-    if (p == 0) {
-        for (uint32_t jb = 0; jb < nit; jb += SYNC_WG) {
-            const uint32_t j = jb + t;
-            bool want = false;
-            if (j < nit) {
-                const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase + j);
-                s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
-                DecState s;
-                s.p = geo.pstart;
-                s.c = 0;
-                s.k = 0;
-                s.q = 0;
-                const RunResult r = run_count<COUNT>(T, s_bits, w0, s, geo.pend, a.gray != 0);
+    if (have) {
+        const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase + t);
+        pend = geo.pend;
+        segfirst = geo.li == 0;
+        fixed = segfirst || (p == 0 && t == 0);
+        if (p == 0) {
+            DecState s;
+            s.p = geo.pstart;
+            s.c = 0;
+            s.k = 0;
+            s.q = 0;
+            used = pack_state(s);
+            r = run_count<COUNT, false>(T, s_bits, w0, s, pend, a.gray != 0);   // exit state only: see below
 #if KPEG_SYNC_STATS
-                st_runs++;
-                st_iters += r.iters;
+            st_runs++;
+            st_iters += r.iters;
 #endif
-                s_X[j + 1] = r.exit_state;
-                if (j >= wu) {
-                    s_cnt[j - wu] = r.cnt;
-                    if (COUNT) s_nrec[j - wu] = r.nrec;
-                }
-                want = geo.li != 0 && j > 0;
-            }
-            push_item(want, j, s_list[0], &s_n[0]);
-        }
-    } else {
-        for (uint32_t j = t; j < nit; j += SYNC_WG) {
-            const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase + j);
-            s_geo[j] = geo.pend | (geo.li == 0 ? 0x80000000u : 0u);
-            s_X[j + 1] = a.X[i0 + j];
-            s_cnt[j] = a.cnt[i0 + j];
-            if (COUNT) s_nrec[j] = a.nrec[i0 + j];
-        }
-        if (t == 0) {
-            s_X[0] = entry;
-            s_list[0][0] = 0;
-            s_n[0] = 1;
+        } else {
+            r.exit_state = a.X[i0 + t];
+            r.cnt = a.cnt[i0 + t];
+            if (COUNT) r.nrec = a.nrec[i0 + t];
         }
     }
-
+    if (p != 0) {
+        // the states the loaded results were decoded from: the left neighbour's exit state (they converged in an earlier
+        // pass); item 0's was this workgroup's assumption
+        const uint64_t left = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)r.exit_state, 1) | ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(r.exit_state >> 32), 1) << 32);
+        used = lane ? left : (t ? (have ? a.X[i0 + t - 1] : 0ull) : a.assumed[g]);
+    }
+    // every wavefront's last exit state so far, before anybody looks
+    if (wave * 64 < nit && lane == min(63u, nit - 1 - wave * 64)) {
+        s_wexit[wave] = r.exit_state;
+        s_wdone[wave] = 0u;
+    }
 #if KPEG_SYNC_STATS
-    __syncthreads();
     const uint64_t tm2 = __builtin_amdgcn_s_memtime();
 #endif
 #ifndef KPEG_ABLATE_NOZERO
@@ -1193,69 +1203,100 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         }
     }
 #endif
-    for (uint32_t round = 0;; ++round) {
-        __syncthreads();
-        const uint32_t n = s_n[round % 3];
-        if (n == 0) break;
-        if (t == 0) s_n[(round + 2) % 3] = 0;
-        const uint16_t* lc = s_list[round & 1];
-        uint16_t* ln = s_list[(round & 1) ^ 1];
-        uint32_t* cn = &s_n[(round + 1) % 3];
+    __syncthreads();
 #if KPEG_SYNC_STATS
-        st_rounds++;
+    const uint64_t tmc = __builtin_amdgcn_s_memtime();
+    uint64_t tr[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t act[6] = {0, 0, 0, 0, 0, 0};
 #endif
-        for (uint32_t qb = 0; qb < n; qb += SYNC_WG) {
-            const uint32_t q = qb + t;
-            bool want = false;
-            uint32_t j = 0;
-            if (q < n) {
-                j = lc[q];
-                // a predecessor re-decoded in this same round may or may not have stored its new
-                // exit state yet: either value is a valid start, and if it moved this item is on
-                // the next list again
-                const uint64_t before = s_X[j + 1];   // (read with the entry state: one LDS round trip, not two)
-                const RunResult r = run_count<COUNT>(T, s_bits, w0, unpack_state(s_X[j]), s_geo[j] & 0x7FFFFFFFu, a.gray != 0);
+    if (wave * 64 < nit) {
+        const uint32_t last_lane = min(63u, nit - 1 - wave * 64);
+        SpinGuard guard(K1_SPIN_TICKS);
+        bool first = true;
+        for (;;) {
+            // the wavefront before: done flag first, then its last exit state (written in the opposite order)
+            const uint32_t prev_done = wave ? __hip_atomic_load(&s_wdone[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 1u;
+            const uint64_t prev_x = wave ? __hip_atomic_load(&s_wexit[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : entry;
+            const uint64_t left = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)r.exit_state, 1) | ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(r.exit_state >> 32), 1) << 32);
+            // (pass 0: the first decode above kept no counts, so everybody decodes once more -- nearly everybody would
+            // anyway, a guessed entry state is almost never the true one; an item with a known entry state from that)
+            const uint64_t in = fixed ? used : (lane ? left : prev_x);
+            const bool again = have && ((p == 0 && first) || in != used);
+            first = false;
+            if (!__ballot(again)) {
+                if (prev_done) break;
+                if (guard.expired()) {   // (cannot happen: the wavefronts of a workgroup run together; bounded like every wait)
+                    if (lane == 0) atomicOr(&a.status[1], KPEG_ERR_TIMEOUT);
+                    break;
+                }
+#if KPEG_SYNC_STATS
+                st_wait++;
+#endif
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            if (again) {
+                r = run_count<COUNT>(T, s_bits, w0, unpack_state(in), pend, a.gray != 0);
+                used = in;
 #if KPEG_SYNC_STATS
                 st_runs++;
                 st_iters += r.iters;
 #endif
-                const bool changed = r.exit_state != before;
-                s_X[j + 1] = r.exit_state;
-                if (j >= wu) {
-                    s_cnt[j - wu] = r.cnt;
-                    if (COUNT) s_nrec[j - wu] = r.nrec;
-                }
-                want = changed && j + 1 < nit && !(s_geo[j + 1] >> 31);
             }
-            push_item(want, j + 1, ln, cn);
+#if KPEG_SYNC_STATS
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if ((int)st_rounds == q) {
+                    tr[q] = __builtin_amdgcn_s_memtime();
+                    act[q] = (uint32_t)__popcll(__ballot(again));
+                }
+            st_rounds++;
+#endif
+            if (lane == last_lane) __hip_atomic_store(&s_wexit[wave], r.exit_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (lane == last_lane) {
+            __hip_atomic_store(&s_wexit[wave], r.exit_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&s_wdone[wave], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 #if KPEG_SYNC_STATS
-    const uint64_t tm3 = __builtin_amdgcn_s_memtime();
-    if (t == 0 && p == 0) {
-        atomicAdd(&a.status[13], (uint32_t)((tm1 - tm0) >> 4));
-        atomicAdd(&a.status[14], (uint32_t)((tm2 - tm1) >> 4));
-        atomicAdd(&a.status[15], (uint32_t)((tm3 - tm2) >> 4));
-    }
-    atomicAdd(&a.status[10], st_runs);
-    atomicAdd(&a.status[12], st_iters);
-    if (t == 0) {
-        atomicAdd(&a.status[8], st_rounds);
-        atomicMax(&a.status[9], st_rounds);
-        atomicAdd(&a.status[11], 1u);
+    {
+        const uint64_t tm3 = __builtin_amdgcn_s_memtime();
+        uint32_t sr = st_runs, si = st_iters, mx = st_iters;
+        for (int o = 32; o > 0; o >>= 1) {
+            sr += (uint32_t)__shfl_xor((int)sr, o);
+            si += (uint32_t)__shfl_xor((int)si, o);
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        }
+        const uint32_t wid = g * (SYNC_WG / 64) + wave;
+        if (lane == 0 && p == 0 && wid < 8192) {
+            unsigned long long* o = &g_ent_stamp[0][wid * 16];
+            o[0] = tm0;
+            o[1] = tm1;
+            o[2] = tm2;
+            o[3] = tm3;
+            o[4] = __builtin_amdgcn_s_memrealtime();
+            o[5] = ((unsigned long long)st_rounds << 32) | sr;
+            o[6] = ((unsigned long long)mx << 32) | si;
+            o[7] = st_wait;
+            o[8] = tmc;
+            for (int q = 0; q < 6; ++q) o[9 + q] = tr[q] | ((unsigned long long)act[q] << 56);
+        }
     }
 #endif
 
     int4 tot = make_int4(0, 0, 0, 0);
     uint32_t trec = 0;
-    if (t < nown) {
-        a.X[i0 + t] = s_X[wu + t + 1];
-        tot = s_cnt[t];
-        a.cnt[i0 + t] = tot;
+    if (have && t >= wu) {
+        a.X[i0 + t - wu] = r.exit_state;
+        tot = r.cnt;
+        a.cnt[i0 + t - wu] = tot;
         if (COUNT) {
-            trec = s_nrec[t];
-            a.nrec[i0 + t] = trec;
+            trec = r.nrec;
+            a.nrec[i0 + t - wu] = trec;
         }
+        if (t == wu) s_edge[0] = segfirst ? X_NONE : used;   // what this workgroup's first own item decoded from
+        if (t == nit - 1) s_edge[1] = r.exit_state;
     }
     // per-workgroup totals for the scan
     for (int o = 32; o > 0; o >>= 1) {
@@ -1279,9 +1320,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
         }
         a.wsum[g] = w;
         a.wrec[g] = wr;
-        const uint64_t last = s_X[nit];
-        const bool known = (s_geo[wu] >> 31) != 0;   // first own sub-sequence opens a restart segment
-        a.assumed[g] = known ? X_NONE : s_X[wu];
+        const uint64_t last = s_edge[1];
+        const bool known = s_edge[0] == X_NONE;   // first own sub-sequence opens a restart segment
+        a.assumed[g] = s_edge[0];
         Xb_cur[g] = last;
         if (a.chained && !mute) {
             __threadfence();
@@ -1360,6 +1401,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     const uint32_t nsub = a.meta->nsub;
     const uint32_t i0 = blockIdx.x * OWN;
     if (i0 >= nsub) return;
+#if KPEG_SYNC_STATS
+    const uint64_t tw0 = __builtin_amdgcn_s_memtime();
+    uint32_t st_steps = 0;
+#endif
     load_tables(&T, a.tabs);
     const uint32_t i = i0 + threadIdx.x;
     const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
@@ -1370,6 +1415,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
+#if KPEG_SYNC_STATS
+    __syncthreads();
+    const uint64_t tw1 = __builtin_amdgcn_s_memtime();
+#endif
     // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup ...
     {
         int4 v = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
@@ -1415,6 +1464,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     }
     __syncthreads();
 
+#if KPEG_SYNC_STATS
+    const uint64_t tw2 = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t err = 0;
     // the block open at this lane's entry, if it ends here: this lane's share of its bound
     bool head = false;
@@ -1508,6 +1560,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         while (p < g.pend && !(k == 0 && b >= blk_limit)) {
             const uint32_t win = br.peek();
             const uint32_t e = lut_finish(T, tb, win, e1);
+#if KPEG_SYNC_STATS
+            st_steps++;
+#endif
             p += e & 31;
             br.consume(e & 31);
             const uint32_t kraw = k + ((e >> 16) & 127);
@@ -1613,6 +1668,9 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             if (k != 0 && (F & F_INSIDE)) err |= 64;   // (bits after the segment's last block are ignored, as the reference ignores them)
         }
     }
+#if KPEG_SYNC_STATS
+    const uint64_t tw3 = __builtin_amdgcn_s_memtime();   // this wavefront's own decode loop is over
+#endif
     __syncthreads();   // every lane has read its s_pre
     s_pre[threadIdx.x] = share;
     __syncthreads();
@@ -1663,6 +1721,28 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         }
     }
     if (err) atomicOr(&a.status[1], err);
+#if KPEG_SYNC_STATS
+    {
+        const uint64_t tw4 = __builtin_amdgcn_s_memtime();
+        uint32_t mx = st_steps, sm = st_steps;
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+            sm += (uint32_t)__shfl_xor((int)sm, o);
+        }
+        const uint32_t wid = blockIdx.x * (SYNC_WG / 64) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && wid < 8192) {
+            unsigned long long* o = &g_ent_stamp[1][wid * 16];
+            o[0] = tw0;
+            o[1] = tw1;
+            o[2] = tw2;
+            o[3] = tw3;
+            o[4] = tw4;
+            o[5] = __builtin_amdgcn_s_memrealtime();
+            o[6] = ((unsigned long long)mx << 32) | sm;
+            o[7] = 0;
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ struct IdctParams {
     uint32_t rec_cap;             // records the buffer holds (bounds what a corrupt table can make a wavefront read)
 };
 
-constexpr uint32_t KPEG_STATUS_WORDS = 16 + 256 + 64;   // [1] error flags, [2] K1 passes, [3] + [272..335] end-of-call tickets, [16..271] counters
+constexpr uint32_t KPEG_STATUS_WORDS = 16 + 256 + 64 + 16;   // [1] error flags, [2] K1 passes, [3] + [272..335] end-of-call tickets, [16..271] counters, [336..351] K2 loop counts of KPEG_SYNC_STATS builds
 
 // End of a call's last kernel, every wavefront: the last one to get here hands the status words to the host
 // mirror (plain posted stores: no read over PCIe) and leaves the device COUNTERS zero for the next call -- no
@@ -117,7 +117,7 @@ __device__ __forceinline__ void status_epilogue(uint32_t* status, uint32_t* h_st
     }
     if (!__shfl((int)last, 0)) return;
     for (uint32_t w = lane; w < KPEG_STATUS_WORDS; w += 64) {
-        const bool ticket = w == 3 || w >= 272;
+        const bool ticket = w == 3 || (w >= 272 && w < 336);
         const uint32_t v = ticket ? 0u : __hip_atomic_load(&status[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         h_status[w] = v;
         if (ticket || (!keep && w != 1)) status[w] = 0;

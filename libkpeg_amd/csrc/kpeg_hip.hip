@@ -503,10 +503,11 @@ static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t 
     if ((f->width / 8) % TILE_MCUS != 0) return false;
     const bool dense = ctx->subseq ? ctx->subseq >= SUBSEQ_DENSE : scan_bytes * 8 >= nmcu * 64 * 4;   // entropy_decode_launch's rule
     if (ctx->coef_layout == 2) return true;
-    // While the dense coefficients (384 bytes per MCU) stay in the 256 MiB Infinity Cache between K2 and K4 the dense layout
-    // costs K4 no HBM reads and no rebuild in LDS: measured equal end to end on the 8K image (190 MiB), and K4 itself 64 against
-    // 73 us.  Beyond that the compact stream wins: 16384x16384 2.05 -> 1.56 ms, 256 x 1080p 141 -> 180 Gpixel/s (profiles/r02).
-    return !dense && nmcu * 384 > ((uint64_t)224 << 20);
+    // Measured end to end (tools/layout_sizes.sh, round 2): 1920x1080 (12 MiB of dense coefficients) 96 us dense against 101
+    // compact, 3840x2160 (48 MiB) 119 / 118, 7680x4320 (190 MiB) 232 / 215, 16384x16384 2.05 / 1.56 ms, 256 x 1080p 141 -> 198
+    // Gpixel/s: the dense layout's 2-byte scatter and its clear cost K2 and K1 more than the rebuild in LDS costs K4 once the
+    // image is large enough for those to show beside the kernels' fixed latencies.
+    return !dense && nmcu * 384 > ((uint64_t)64 << 20);
 }
 
 static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint32_t nmcu,
@@ -1079,6 +1080,14 @@ extern "C" int kpeg_hip_debug_words(kpeg_hip_ctx* ctx, uint32_t* out, int n)
     return KPEG_HIP_OK;
 }
 
+#if KPEG_SYNC_STATS
+// experiment builds only: per-wavefront timelines of K1 pass 0 (which = 0) and K2 (1), tools/sync_dbg.py
+extern "C" int kpeg_hip_debug_entropy_stamps(int which, unsigned long long* out, int n)
+{
+    if (which < 0 || which > 1 || n > 8192 * 16) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kpeg_dev::g_ent_stamp), (size_t)n * 8, (size_t)which * 8192 * 16 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
 #ifdef KPEG_K4_STAMP
 // diagnostic build only (tools/k4_clock.py): per-wavefront start/end stamps of the last K4 launch
 extern "C" int kpeg_hip_debug_k4_stamps(unsigned long long* out, int n)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--width", type=int, default=bench.W8K)
     ap.add_argument("--height", type=int, default=bench.H8K)
     ap.add_argument("--idct-mode", type=int, default=0, help="kpeg_hip_set_idct_mode: 2 = unsafe pixels are queued but not re-evaluated (wrong pixels: what the queueing alone costs)")
+    ap.add_argument("--layouts", default="0", help="comma list of coefficient layouts per variant: 0 auto, 1 dense, 2 compact (debug key 7)")
     args = ap.parse_args()
     import torch
     import libkpeg_amd as K
@@ -56,14 +57,24 @@ def main():
     d_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     ctxs = {}
+    layouts = [int(x) for x in args.layouts.split(",")]
     for name, lib in libs.items():
-        c = K.Context(0, lib=lib)
-        c.set_stream(stream)
-        c.set_idct_mode(args.idct_mode)
-        ctxs[name] = c
+        for lay in layouts:
+            c = K.Context(0, lib=lib)
+            c.set_stream(stream)
+            c.set_idct_mode(args.idct_mode)
+            if lay:
+                assert lib.kpeg_hip_debug_set(c._h, 7, lay) == 0
+            ctxs[name + ("" if len(layouts) == 1 else "@%d" % lay)] = c
     first = next(iter(ctxs.values()))
     first.entropy_decode_dev(frame, d_scan.data_ptr(), d_scan.numel(), d_coef.data_ptr())
     first.sync()
+
+    def sync(c):
+        try:
+            c.sync()
+        except K.KpegError:      # an ablated variant may decode garbage: only its timing is of interest
+            pass
 
     def run(c):
         if args.mode == "k4":
@@ -75,26 +86,26 @@ def main():
     for name, c in ctxs.items():
         d_rgb.zero_()
         run(c)
-        c.sync()
+        sync(c)
         ok[name] = None if want is None else hashlib.sha256(d_rgb.cpu().numpy().tobytes()).hexdigest() == want
     res = {n: {"wall": [], "k": {}} for n in ctxs}
     for r in range(args.rounds):
         for name, c in ctxs.items():
             for _ in range(3):
                 run(c)
-            c.sync()
+            sync(c)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 run(c)
             torch.cuda.synchronize()
             res[name]["wall"].append((time.perf_counter() - t0) / args.steps * 1e3)
-            c.sync()
+            sync(c)
             c.set_profiling(True)
             acc = {}
             for _ in range(5):
                 run(c)
-                c.sync()
+                sync(c)
                 for k, v in c.timings().items():
                     acc[k] = acc.get(k, 0.0) + v / 5
             c.set_profiling(False)
