@@ -61,6 +61,11 @@ namespace kpeg
             /// Extension, off by default: accept one-component (grayscale) baseline files.  The reference reads three
             /// component triples whatever SOF0's count says (src/Decoder.cpp:339) and fails on them.
             void setGrayscaleSupport( bool on ) { allowGray_ = on; }
+            /// Extension, off by default: accept widths and heights that are not multiples of 8.  The reference decodes
+            /// (w * h) / 64 MCUs and then tiles ceil(w / 8) * ceil(h / 8) of them (src/Decoder.cpp:670, src/Image.cpp:26-68):
+            /// it reads past its MCU vector.  Here all MCUs of the padded picture are decoded and the picture is cropped
+            /// the way Image::createImageFromMCUs crops it.
+            void setAnySizeSupport( bool on ) { allowAnySize_ = on; }
             /// Parse only: stop at the seam and leave the tables for frameInfo().
             void setParseOnly( bool on ) { parseOnly_ = on; }
             /// Tables and geometry as handed to the GPU path; valid after decodeImageFile().
@@ -108,6 +113,7 @@ namespace kpeg
             UInt32 restartInterval_;
             bool allowDRI_, parseOnly_;
             bool allowGray_ = false;
+            bool allowAnySize_ = false;
             int components_ = 3;
     };
 }

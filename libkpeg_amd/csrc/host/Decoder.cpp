@@ -406,7 +406,7 @@ namespace kpeg
     {
         kpeg_frame f;
         const unsigned w = image_.getWidth(), h = image_.getHeight();
-        return !scan_.empty() && sosCount_ == 1 && frameInfo( &f ) && w != 0 && h != 0 && !( w & 7 ) && !( h & 7 );
+        return !scan_.empty() && sosCount_ == 1 && frameInfo( &f ) && w != 0 && h != 0 && ( allowAnySize_ || ( !( w & 7 ) && !( h & 7 ) ) );
     }
 
     JPEGDecoder::ResultCode JPEGDecoder::decodeScanData()
@@ -418,7 +418,7 @@ namespace kpeg
         }
         kpeg_frame f;
         const unsigned w = image_.getWidth(), h = image_.getHeight();
-        if ( sosCount_ != 1 || !frameInfo( &f ) || w == 0 || h == 0 || ( w & 7 ) || ( h & 7 ) )
+        if ( sosCount_ != 1 || !frameInfo( &f ) || w == 0 || h == 0 || ( !allowAnySize_ && ( ( w & 7 ) || ( h & 7 ) ) ) )
         {
             LOG(Logger::Level::ERROR) << "[ FATAL ] Stream is outside what libKPEG decodes without undefined behaviour "
                                          "(two quantisation tables id 0,1; four Huffman tables id 0/1; one scan; "
@@ -434,7 +434,7 @@ namespace kpeg
         }
         int rc;
         const std::vector<kpeg_hip_ctx*>& many = f.restart_interval ? hip::contexts( &why ) : std::vector<kpeg_hip_ctx*>();
-        if ( many.size() > 1 && ( w / 8 ) % f.restart_interval == 0 )   // every MCU row starts a restart interval
+        if ( many.size() > 1 && !( w & 7 ) && !( h & 7 ) && ( w / 8 ) % f.restart_interval == 0 )   // every MCU row starts a restart interval
         {
             // extension (the reference rejects DRI): a restart-interval image goes over $KPEG_HIP_DEVICES GPUs as row stripes,
             // every GPU downloads its own rows

@@ -4,7 +4,7 @@
 // must end in ".jpg" (isValidFilename), the PPM lands next to the input, kpeg.log is created
 // in the working directory.  The encode direction (`kpeg in.ppm out.jpg`) belongs to the
 // reference's unfinished encoder and is out of scope here; it reports that and exits.
-// Extensions: `--allow-dri` accepts streams with restart markers, `--allow-gray` one-component files; `--batch` takes any number of files and
+// Extensions: `--allow-dri` accepts streams with restart markers, `--allow-gray` one-component files, `--allow-any-size` widths and heights that are not multiples of 8; `--batch` takes any number of files and
 // directories and decodes files of identical geometry and tables together (kpeg::decodeFiles).
 #include <cstdlib>
 #include <cstring>
@@ -29,10 +29,11 @@ static void printHelp()
     std::cout << "--allow-dri <filename.jpg>      : same, accepting restart markers (extension)" << std::endl;
     std::cout << "--batch [--allow-dri] <files and directories...> : Decompress many JPEG images (extension)" << std::endl;
     std::cout << "--allow-gray <filename.jpg>     : ... accepting one-component (grayscale) files (extension)" << std::endl;
+    std::cout << "--allow-any-size <filename.jpg> : ... accepting widths and heights that are not multiples of 8 (extension)" << std::endl;
     std::cout << "-h                              : Print this help message and exit" << std::endl;
 }
 
-static int decodeJPEG( const std::string& filename, bool allowDRI, bool allowGray = false )
+static int decodeJPEG( const std::string& filename, bool allowDRI, bool allowGray = false, bool allowAnySize = false )
 {
     if ( !kpeg::isValidFilename( filename ) )
     {
@@ -42,6 +43,7 @@ static int decodeJPEG( const std::string& filename, bool allowDRI, bool allowGra
     kpeg::JPEGDecoder decoder;
     decoder.setRestartMarkerSupport( allowDRI );
     decoder.setGrayscaleSupport( allowGray );
+    decoder.setAnySizeSupport( allowAnySize );
     decoder.open( filename );
     if ( decoder.decodeImageFile() == kpeg::JPEGDecoder::ResultCode::DECODE_DONE )
         decoder.dumpRawData();
@@ -100,6 +102,8 @@ int main( int argc, char** argv )
             return decodeJPEG( argv[2], true );
         if ( argc == 3 && std::string( argv[1] ) == "--allow-gray" )
             return decodeJPEG( argv[2], false, true );
+        if ( argc == 3 && std::string( argv[1] ) == "--allow-any-size" )
+            return decodeJPEG( argv[2], false, false, true );
         if ( argc == 3 )
         {
             LOG(kpeg::Logger::Level::ERROR) << "The PPM->JPEG encoder of libKPEG is unfinished upstream and is not part of this build." << std::endl;

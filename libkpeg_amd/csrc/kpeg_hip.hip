@@ -47,6 +47,8 @@ struct kpeg_hip_ctx {
     size_t scan_cap = 0;
     void* d_rgb = nullptr;
     size_t rgb_cap = 0;
+    void* d_pad = nullptr;      // any-size extension: the padded picture K4 writes before the crop
+    size_t pad_cap = 0;
     void* d_ebound = nullptr;  // per-block error bounds for K4 (written by K2 or k_ebound)
     size_t ebound_cap = 0;
     // compact coefficient stream between K2 and K4 (sparse streams whose MCU rows are whole K4 tiles): records, DC values, first record of every tile
@@ -228,6 +230,7 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     if (ctx->d_coef) (void)hipFree(ctx->d_coef);
     if (ctx->d_scan) (void)hipFree(ctx->d_scan);
     if (ctx->d_rgb) (void)hipFree(ctx->d_rgb);
+    if (ctx->d_pad) (void)hipFree(ctx->d_pad);
     if (ctx->d_ebound) (void)hipFree(ctx->d_ebound);
     if (ctx->d_rec) (void)hipFree(ctx->d_rec);
     if (ctx->d_dc16) (void)hipFree(ctx->d_dc16);
@@ -355,11 +358,13 @@ extern "C" int kpeg_hip_get_timings(kpeg_hip_ctx* ctx, kpeg_hip_timings* out)
 }
 
 // ---------------------------------------------------------------------------------------------
-static int check_frame(kpeg_hip_ctx* ctx, const kpeg_frame* f)
+// any_size: the entry points of the any-size extension (whole-image decodes) take widths and heights that are not
+// multiples of 8; everything else keeps the reference's contract.
+static int check_frame(kpeg_hip_ctx* ctx, const kpeg_frame* f, bool any_size = false)
 {
     if (!ctx || !f) return KPEG_HIP_E_ARG;
-    if (f->width == 0 || f->height == 0 || (f->width & 7) || (f->height & 7) || f->width > 65535 || f->height > 65535) {
-        ctx->last_error = "width/height must be non-zero multiples of 8 (SURVEY.md A.1)";
+    if (f->width == 0 || f->height == 0 || (!any_size && ((f->width & 7) || (f->height & 7))) || f->width > 65535 || f->height > 65535) {
+        ctx->last_error = any_size ? "width/height must be 1..65535" : "width/height must be non-zero multiples of 8 (SURVEY.md A.1)";
         return KPEG_HIP_E_ARG;
     }
     if (f->components != 0 && f->components != 1 && f->components != 3) {
@@ -611,16 +616,63 @@ extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f
     return finish_async(ctx, ctx->idct_mode != 1);
 }
 
+// Any-size extension (Image::createImageFromMCUs, Image.cpp:26-27,73-84: pad to whole MCUs, tile, pop the extra columns
+// and rows): rows [0, H) x bytes [0, 3 W) of the padded picture, four destination bytes per thread.
+__global__ void k_crop(const uint8_t* __restrict__ src, uint32_t spitch, uint8_t* __restrict__ dst, uint32_t dpitch, uint64_t total)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;
+    uint32_t y = (uint32_t)(i / dpitch), x = (uint32_t)(i - (uint64_t)y * dpitch), w = 0;
+    const uint32_t nb = (uint32_t)(total - i < 4 ? total - i : 4);
+    for (uint32_t k = 0; k < nb; ++k) {
+        if (x == dpitch) {
+            x = 0;
+            y++;
+        }
+        w |= (uint32_t)src[(size_t)y * spitch + x] << (8 * k);
+        x++;
+    }
+    if (nb == 4) {
+        *reinterpret_cast<uint32_t*>(dst + i) = w;   // (dst is 8-byte aligned: launch_idct's rule for every destination)
+    } else {
+        for (uint32_t k = 0; k < nb; ++k) dst[i + k] = (uint8_t)(w >> (8 * k));
+    }
+}
+
+static int decode_any_size(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint8_t* d_rgb)
+{
+    int rc = check_frame(ctx, f, true);
+    if (rc) return rc;
+    if (!d_scan || !scan_len || !d_rgb) return KPEG_HIP_E_ARG;
+    if (reinterpret_cast<uintptr_t>(d_rgb) & 7) {
+        ctx->last_error = "rgb buffer must be 8-byte aligned";
+        return KPEG_HIP_E_ARG;
+    }
+    kpeg_frame fp = *f;
+    fp.width = (f->width + 7) & ~7u;
+    fp.height = (f->height + 7) & ~7u;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = grow(ctx, &ctx->d_pad, &ctx->pad_cap, (size_t)fp.width * fp.height * 3))) return rc;
+    rc = kpeg_hip_decode_stripe_dev(ctx, &fp, d_scan, scan_len, 0, fp.height / 8, (uint8_t*)ctx->d_pad);
+    if (rc) return rc;
+    const uint64_t total = (uint64_t)f->width * f->height * 3;
+    hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_pad, fp.width * 3,
+                       d_rgb, f->width * 3, total);
+    HIPCHK(ctx, hipGetLastError());
+    return KPEG_HIP_OK;
+}
+
 extern "C" int kpeg_hip_decode_scan_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len,
                                         uint8_t* d_rgb)
 {
     if (!f) return KPEG_HIP_E_ARG;
+    if ((f->width & 7) || (f->height & 7)) return decode_any_size(ctx, f, d_scan, scan_len, d_rgb);
     return kpeg_hip_decode_stripe_dev(ctx, f, d_scan, scan_len, 0, f->height / 8, d_rgb);
 }
 
 extern "C" int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* scan, size_t scan_len, uint8_t* rgb)
 {
-    int rc = check_frame(ctx, f);
+    int rc = check_frame(ctx, f, true);
     if (rc) return rc;
     if (!scan || !scan_len || !rgb) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -636,7 +688,7 @@ extern "C" int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
 
 extern "C" int kpeg_hip_decode_scan_resident(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* scan, size_t scan_len)
 {
-    int rc = check_frame(ctx, f);
+    int rc = check_frame(ctx, f, true);
     if (rc) return rc;
     if (!scan || !scan_len) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -651,7 +703,7 @@ extern "C" int kpeg_hip_decode_scan_resident(kpeg_hip_ctx* ctx, const kpeg_frame
 
 extern "C" int kpeg_hip_download_bands(kpeg_hip_ctx* ctx, const kpeg_frame* f, uint32_t band_rows, kpeg_hip_band_sink sink, void* user)
 {
-    int rc = check_frame(ctx, f);
+    int rc = check_frame(ctx, f, true);
     if (rc) return rc;
     if (!sink) return KPEG_HIP_E_ARG;
     const size_t pitch = (size_t)f->width * 3, rbytes = pitch * f->height;

@@ -624,8 +624,7 @@ void kpeg_oracle_idct_colour(const int16_t* coef, const uint16_t qt[2][64], uint
     }
 }
 
-int kpeg_oracle_decode(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width,
-                       uint32_t* height, int nthreads)
+static int decode_impl(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads, int any_size)
 {
     kpeg_oracle_jfif j;
     int st = kpeg_oracle_parse(file, n, &j);
@@ -634,12 +633,14 @@ int kpeg_oracle_decode(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* w
         return st;
     }
     /* contract: SURVEY.md A.1 */
-    if (!j.scan || j.scan_len == 0 || j.width == 0 || j.height == 0 || (j.width & 7) || (j.height & 7) ||
+    if (!j.scan || j.scan_len == 0 || j.width == 0 || j.height == 0 || (!any_size && ((j.width & 7) || (j.height & 7))) ||
         !have_tables(&j)) {
         kpeg_oracle_jfif_free(&j);
         return KPEG_ORACLE_OUT_OF_CONTRACT;
     }
-    uint32_t nmcu = (j.width * j.height) / 64; /* Decoder.cpp:670 */
+    /* any_size (extension): the padded size Image::createImageFromMCUs tiles (Image.cpp:26-27) */
+    const uint32_t pw = (j.width + 7) & ~7u, ph = (j.height + 7) & ~7u;
+    uint32_t nmcu = any_size ? (pw / 8) * (ph / 8) : (j.width * j.height) / 64; /* Decoder.cpp:670 */
     uint8_t* bits = (uint8_t*)malloc(j.scan_len);
     size_t nb = kpeg_oracle_unstuff(j.scan, j.scan_len, bits);
     int16_t* coef = (int16_t*)malloc((size_t)nmcu * 192 * sizeof(int16_t));
@@ -650,14 +651,32 @@ int kpeg_oracle_decode(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* w
         kpeg_oracle_jfif_free(&j);
         return rc;
     }
-    uint8_t* out = (uint8_t*)malloc((size_t)j.width * j.height * 3);
-    kpeg_oracle_idct_colour(coef, (const uint16_t(*)[64])j.qt, j.width, j.height, out, nthreads);
+    uint8_t* out = (uint8_t*)malloc((size_t)pw * ph * 3);
+    kpeg_oracle_idct_colour(coef, (const uint16_t(*)[64])j.qt, pw, ph, out, nthreads);
     free(coef);
+    if (pw != j.width || ph != j.height) {
+        /* the columns and rows Image::createImageFromMCUs pops (Image.cpp:73-84) */
+        for (uint32_t y = 0; y < j.height; ++y) memmove(out + (size_t)y * j.width * 3, out + (size_t)y * pw * 3, (size_t)j.width * 3);
+    }
     *rgb = out;
     *width = j.width;
     *height = j.height;
     kpeg_oracle_jfif_free(&j);
     return KPEG_ORACLE_DECODE_DONE;
+}
+
+int kpeg_oracle_decode(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads)
+{
+    return decode_impl(file, n, rgb, width, height, nthreads, 0);
+}
+
+/* Extension: width / height that are not multiples of 8.  The reference computes the MCU count as (w * h) / 64
+ * (Decoder.cpp:670), decodes that many and then tiles ceil(w / 8) * ceil(h / 8) of them (Image.cpp:26-68): it reads past
+ * the end of its MCU vector -- undefined behaviour, nothing to pin to.  PARITY UNPINNED: here every MCU of the padded
+ * picture is decoded (what a JFIF encoder writes) and the picture is cropped the way createImageFromMCUs crops it. */
+int kpeg_oracle_decode_any_size(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads)
+{
+    return decode_impl(file, n, rgb, width, height, nthreads, 1);
 }
 
 size_t kpeg_oracle_ppm_header(uint32_t width, uint32_t height, char* buf, size_t cap)
