@@ -54,7 +54,8 @@ typedef struct kpeg_dht {
 
 /* What the marker parser knows when it reaches the seam. */
 typedef struct kpeg_frame {
-    uint32_t width, height;     /* SOF0 dimensions (Decoder.cpp:361); multiples of 8          */
+    uint32_t width, height;     /* SOF0 dimensions (Decoder.cpp:361); multiples of 8 -- any
+                                   size 1..65535 at the whole-image entry points, see below   */
     uint16_t qt[2][64];         /* m_QTables[0], [1]: zig-zag order as stored (Decoder.cpp:278)
                                    [0] -> Y, [1] -> Cb and Cr (hard-wired, MCU.cpp:110)       */
     kpeg_dht dht[2][2];         /* m_huffmanTable[class 0=DC,1=AC][id]; id 0 -> Y,
@@ -120,6 +121,12 @@ int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const int16
  *         the FF D9; still byte-stuffed. */
 int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len,
                          uint8_t* rgb);
+/* Extension (off by default in the host parser, KPEG_PARSE_ALLOW_ANY_SIZE): kpeg_hip_decode_scan, _scan_dev, _scan_resident
+ * and kpeg_hip_download_bands also take widths / heights that are not multiples of 8.  All ceil(w/8) * ceil(h/8) MCUs of
+ * the padded picture are decoded and the rows and columns Image::createImageFromMCUs pops (Image.cpp:26-27,73-84) are
+ * cropped on the device; rgb is height*width*3 bytes as ever.  (The reference itself decodes (w*h)/64 MCUs and tiles
+ * more than it has: undefined behaviour, so nothing to be bit-identical with but its output for the same scan at the
+ * padded size -- which is what the tests pin.)  Every other entry point keeps the multiple-of-8 contract. */
 
 /* The same decode with the pixels left on the device, in a buffer the context owns (valid until the context's next
  * decode), and their download in row bands through two pinned bounce buffers: while band k+1 crosses PCIe, `sink` is
