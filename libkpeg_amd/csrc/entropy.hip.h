@@ -102,8 +102,10 @@ constexpr int POOL_SUBS = KPEG_POOL_SUBS;             // second-level tables sha
 //   [23] no such code                    [24] DC symbol with a run nibble (outside the contract)
 //   [25] DC symbol other than 0x00: the block keeps its AC terms (quirk Q1)
 //   [26] AC symbol that carries a non-zero coefficient (category > 0): one record of the compact coefficient stream
+//   [27] AC symbol other than EOB (a run: with a coefficient, or ZRL): must not run past the end of its block
 //   [31] code longer than LUT_BITS: [15:0] = second-level table in the pool, E_SEARCH = none left
-constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_KEEP = 1u << 25, E_REC = 1u << 26, E_LONG = 1u << 31;
+constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_KEEP = 1u << 25, E_REC = 1u << 26, E_ACSYM = 1u << 27,
+                   E_LONG = 1u << 31;
 constexpr uint32_t E_SEARCH = 0xFFFFu;
 
 __host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool isdc)
@@ -111,7 +113,8 @@ __host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool 
     const uint32_t cat = sym & 15, run = sym >> 4;
     const uint32_t kadv = isdc ? 65u : (sym == 0 ? 64u : run + 1);
     return (len + cat) | (len << 5) | (cat << 10) | (isdc ? E_ISDC : 0u) | (sym == 0 ? E_ZERO : 0u) | (kadv << 16) |
-           ((isdc && run) ? E_DCRUN : 0u) | ((isdc && sym != 0) ? E_KEEP : 0u) | ((!isdc && cat != 0) ? E_REC : 0u);
+           ((isdc && run) ? E_DCRUN : 0u) | ((isdc && sym != 0) ? E_KEEP : 0u) | ((!isdc && cat != 0) ? E_REC : 0u) |
+           ((!isdc && sym != 0) ? E_ACSYM : 0u);
 }
 // no such code: keep moving by 16 bits (only a speculative decode or a corrupt stream gets here;
 // the reference would never leave its bit loop, Decoder.cpp:704-748)
@@ -128,6 +131,7 @@ struct EntropyTables {  // built on the host per frame, copied to the device whe
     uint8_t symbols[4][256];
     uint8_t zz[64];                  // zig-zag -> natural
     float mscale_zz[2][64];          // 0.25 * cc[u][v] * Q[u][v] by zig-zag position: K4's input scale
+    float2 zzm[2][64];               // K2's one read per coefficient: .x = mscale_zz, .y (bits) = natural position << 8 | outside the 2x2 corner << 31
     float q00[2];                    // Q[0][0] of both tables
     float pad16[2];                  // (the tables are copied to LDS in 16-byte pieces)
 };
@@ -145,6 +149,11 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
         }
         t->mscale_zz[tq][0] = 0.25f * (0x1.fffffep-2f * (float)f->qt[tq][0]);  // the reference's own cc[0][0] (Transform.cpp), as K4 uses it
         t->q00[tq] = (float)f->qt[tq][0];
+        for (int k = 0; k < 64; ++k) {
+            const uint32_t bits = ((uint32_t)KPEG_ZZ_TO_NATURAL[k] << 8) | ((k == 0 || k == 1 || k == 2 || k == 4) ? 0u : 0x80000000u);
+            t->zzm[tq][k].x = t->mscale_zz[tq][k];
+            std::memcpy(&t->zzm[tq][k].y, &bits, 4);
+        }
     }
     int nsub = 0;
     for (int cls = 0; cls < 2; ++cls)
@@ -677,6 +686,7 @@ struct LdsTables {
     uint8_t symbols[4][256];
     uint8_t zz[64];
     float mscale_zz[2][64];
+    float2 zzm[2][64];
     float q00[2];
     float pad16[2];
 };
@@ -1508,7 +1518,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         }
         const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
         const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
-        const bool gray = a.gray != 0;                 // one block per MCU, stored as the MCU's luma block (stride 3)
+        const bool gray = !COMPACT && a.gray != 0;     // one block per MCU, stored as the MCU's luma block (stride 3); dense layout only
         const uint32_t bstride = gray ? 3u : 1u;
         const uint32_t blk_limit = gray ? seg_mcus : seg_mcus * 3;   // blocks of this segment
         uint32_t b = (uint32_t)pre.x;                  // blocks started so far, within the segment
@@ -1523,20 +1533,24 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         int pd0 = cb == 0 ? pre.y : (cb == 1 ? pre.z : pre.w);
         int pd1 = cb == 0 ? pre.z : (cb == 1 ? pre.w : pre.y);
         int pd2 = cb == 0 ? pre.w : (cb == 1 ? pre.y : pre.z);
-        // state of the block in progress, as bits of one register (booleans would live in SGPR masks
-        // that the compiler re-merges every iteration)
-        constexpr uint32_t F_KEEP = 1;       // keeps its AC terms: quirk Q1, a DC "EOB" drops them (MCU.cpp:97-100)
-        constexpr uint32_t F_STARTED = 2;    // began in this lane
-        constexpr uint32_t F_NONCORNER = 4;  // has a non-zero AC term outside the 2x2 corner (natural 1, 8, 9 = zig-zag 1, 2, 4)
-        constexpr uint32_t F_OVER = 1u << 8; // error: a run went past the end of a block
-        constexpr uint32_t F_HEAD = 1u << 9, F_HEAD_NONCORNER = 1u << 10;   // the block open at entry ended here; its F_NONCORNER
-        uint32_t F = s.q ? F_KEEP : 0u;
+        // State of the block in progress.  A lane that enters inside a block carries that block as its HEAD: the first
+        // block end it meets closes a block somebody else began (its bound is settled after the loop, from the shares);
+        // every later block began here with its DC symbol.
+        // (flags as bits of one register: booleans carried round the loop would live in SGPR masks that the compiler
+        // re-merges every iteration, a dozen scalar instructions each time)
+        constexpr uint32_t FL_INHEAD = 1;    // the block in progress began in an earlier lane
+        constexpr uint32_t FL_HADHEAD = 2;   // ... and ended here
+        constexpr uint32_t FL_HNC = 4;       // ... with a term outside the 2x2 corner
+        constexpr uint32_t FL_LAST = 8;      // the segment's last block ended here
+        uint32_t fl = s.k != 0 ? FL_INHEAD : 0u;
+        uint32_t keep = s.q ? E_REC : 0u;    // E_REC while the block keeps its AC terms: quirk Q1, a DC "EOB" drops them (MCU.cpp:97-100)
+        uint32_t ncw = 0;                    // bit 31: a non-zero AC term outside the 2x2 corner (natural 1, 8, 9 = zig-zag 1, 2, 4)
         uint32_t ebits = 0;                  // E_BAD / E_DCRUN of every entry met
+        uint32_t over = 0;                   // entries whose run went past the end of a block (E_ACSYM of them)
         uint32_t dcrange = 0;
         // compact stream: where this lane's records go (K1 counted them: the scan gives every lane its first ordinal), and
         // which block of which K4 tile the next block to start is (global block gbase + b = 24 tile + bmn)
         uint32_t ord = 0, ord_end = 0, bmn = 0, tn = 0, bm_cur = 0;
-        bool last_block_ended_here = false;
         if (COMPACT) {
             ord = a.wrec[blockIdx.x] + s_prer[threadIdx.x];
             ord_end = min(ord + a.nrec[i], a.rec_cap);
@@ -1549,15 +1563,20 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
         int nnz = 0;
         const uint32_t gbase = seg_mcu0 * 3;
         uint32_t gb = gbase + (b ? b - 1 : 0) * bstride;          // block in progress
-        if (k != 0 && b == 0) err |= 64;                // inside a block before the segment's first one began
-        // a corrupt stream can count more blocks than the segment has: nothing is written for those
-        constexpr uint32_t F_INSIDE = 1u << 11;         // the block in progress lies inside the segment
-        if (b >= 1 && b - 1 < blk_limit) F |= F_INSIDE;
-#if KPEG_ABLATE_W == 2
-        if (a.nmcu == 0)
-#endif
+        uint32_t cur_chroma = tb >= 2 * LUT_BYTES ? 1u : 0u;      // ... and whether it is a chroma block
+        // What this lane may touch: a corrupt stream can count more blocks than the segment has.  No block beyond the
+        // segment's last is ever started (the loop ends with the block that completes the segment), so only the block in
+        // progress at entry can lie outside: such a lane does nothing.
+        uint32_t pend = g.pend;
+        if (k == 0 && b >= blk_limit) pend = 0;                   // the segment is complete
+        if (k != 0 && !(b >= 1 && b - 1 < blk_limit)) {
+            if (b == 0) err |= 64;                                // inside a block before the segment's first one began
+            pend = 0;                                             // (else: bits after the segment's last block, ignored as the reference ignores them)
+            fl = 0;
+        }
+        const float m00_l = T.zzm[0][0].x, m00_c = T.zzm[1][0].x;
         uint32_t e1 = lut_first(T, tb, br.peek());
-        while (p < g.pend && !(k == 0 && b >= blk_limit)) {
+        while (p < pend) {
             const uint32_t win = br.peek();
             const uint32_t e = lut_finish(T, tb, win, e1);
 #if KPEG_SYNC_STATS
@@ -1568,22 +1587,25 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
             const uint32_t kraw = k + ((e >> 16) & 127);
             const bool adv = kraw >= 64;
             const bool isdc = (e & E_ISDC) != 0;
-            const uint32_t tdc = tb >= 2 * LUT_BYTES ? 1u : 0u;   // chroma tables
+            const bool chroma = tb >= 2 * LUT_BYTES;              // the table in use: chroma tables
             k = adv ? ((e >> 14) & 1u) : kraw;
             tb += adv ? LUT_BYTES : 0u;
             tb = tb == tb_wrap ? 0u : tb;
             e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way
             const int ext = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
             ebits |= e;
-            // a DC symbol opens block gbase + b; its value is coefficient 0
-            const int n = pd0 + ext;
+            over |= kraw > 64 ? e : 0u;
             if (isdc) {
+                // a DC symbol opens block gbase + b; its value is coefficient 0 (DC predictors: DCDiff[c] += zz[0], MCU.cpp:107)
+                const int n = pd0 + ext;
                 dcrange |= (uint32_t)(n + 32768);   // bits above 15: the absolute DC does not fit the int16 coefficient layout
                 pd0 = gray ? n : pd1;
                 pd1 = gray ? pd1 : pd2;
                 pd2 = gray ? pd2 : n;
                 gb = gbase + b * bstride;
                 b++;
+                cur_chroma = chroma ? 1u : 0u;
+                keep = (e >> 25) & 1u ? E_REC : 0u; // E_KEEP
                 if (COMPACT) {
                     bm_cur = bmn;
                     if (bmn == 0 && tn <= a.ntiles) a.tile_start[tn] = ord;   // this tile's records begin here
@@ -1592,80 +1614,75 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
                         bmn = 0;
                         tn++;
                     }
+                    a.dc16[gb] = (int16_t)n;
+                } else {
+                    a.coef[(size_t)gb << 6] = (int16_t)n;
                 }
-                F = (F & (F_OVER | F_HEAD | F_HEAD_NONCORNER)) | F_STARTED | F_INSIDE | ((e >> 25) & 1u);   // E_KEEP -> F_KEEP; b < blk_limit here
-            }
-            const int v = isdc ? n : ext;
-            // zig-zag position: DC 0; AC kraw - 1, which is >= 64 for an EOB, "no such code" and a run past the end
-            const uint32_t posraw = kraw - 1, pos = posraw & 63;
-            if (!isdc && !(e & E_ZERO) && kraw > 64) F |= F_OVER;
-            if ((F & F_INSIDE) && (isdc || ((F & F_KEEP) && posraw < 64))) {
-#if KPEG_ABLATE_W != 1 && KPEG_ABLATE_W != 3
+                // == the terms of block_ebound()'s A in idct_colour.hip.h (DC: 0.25 cc00 Q00, any rounding order is inside U's slack)
+                Asum = fabsf((float)n * (chroma ? m00_c : m00_l));
+                nnz = 0;
+                ncw = 0;
+            } else if ((e & keep) && kraw <= 64) {
+                // a non-zero AC coefficient (category > 0) at zig-zag position kraw - 1 of a block that keeps its AC terms:
+                // exactly what K1 counted as a record
+                const float2 zm = T.zzm[chroma ? 1 : 0][kraw - 1];   // scale, natural position << 8 | outside-the-corner << 31
+                const uint32_t zw = __float_as_uint(zm.y);
                 if (COMPACT) {
-                    if (isdc) {
-                        a.dc16[gb] = (int16_t)v;
-                    } else if (v != 0 && ord < ord_end) {   // (ord < ord_end always holds: K1 counted by the same rule)
-                        a.rec[ord] = ((uint32_t)v << 16) | ((uint32_t)T.zz[pos] << 8) | bm_cur;
+                    if (ord < ord_end) {   // (always: K1 counted by the same rule)
+                        a.rec[ord] = ((uint32_t)ext << 16) | (zw & 0x3F00u) | bm_cur;
                         ord++;
                     }
                 } else {
-                    a.coef[((size_t)gb << 6) | T.zz[pos]] = (int16_t)v;
+                    a.coef[((size_t)gb << 6) | ((zw >> 8) & 63u)] = (int16_t)ext;
                 }
-#endif
-                // == the terms of block_ebound()'s A in idct_colour.hip.h (DC: 0.25 cc00 Q00, any rounding order is inside U's slack)
-                Asum += fabsf((float)v * T.mscale_zz[tdc][pos]);
-                if (v != 0 && !isdc) {
-                    nnz++;
-                    if (!((0x16u >> min(pos, 31u)) & 1u)) F |= F_NONCORNER;
-                }
+                Asum += fabsf((float)ext * zm.x);
+                nnz++;
+                ncw |= zw;
             }
             if (adv && !isdc) {
                 // the block is complete
-                if (COMPACT && b == blk_limit && (F & F_INSIDE)) last_block_ended_here = true;
-                if (!(F & F_INSIDE)) {
-                    // a block the segment does not have (corrupt stream): no bound to write
-                } else if (F & F_STARTED) {
-                    // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
-                    const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
-                    // even mantissa, rounded up; lowest bit = chroma samples may leave the f32 colour range (Asum >= 249)
-                    const uint32_t Eb = ((__float_as_uint(E) + 1u) & ~1u) | ((tdc && !(Asum < 249.0f)) ? 1u : 0u);
-                    const float Ef = __uint_as_float(Eb);
-#if KPEG_ABLATE_W != 3
-                    a.ebound[gb] = !(Asum < 4000.0f) ? __builtin_inff() : ((F & F_NONCORNER) ? Ef : -Ef);
-#else
-                    if (E == 123.0f) a.ebound[gb] = E;
-#endif
-                } else {
-                    F |= F_HEAD | ((F & F_NONCORNER) ? F_HEAD_NONCORNER : 0u);
+                if (b >= blk_limit) {
+                    pend = 0;                       // ... and with it the segment: nothing after it is this lane's (or anybody's)
+                    fl |= FL_LAST;
+                }
+                if (fl & FL_INHEAD) {
+                    fl = (fl & ~FL_INHEAD) | FL_HADHEAD | ((int)ncw < 0 ? FL_HNC : 0u);
                     hA = Asum;
                     hnnz = nnz;
                     hgb = gb;
-                    hchroma = (int)tdc;
+                    hchroma = (int)cur_chroma;
+                } else {
+                    // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
+                    const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
+                    // even mantissa, rounded up; lowest bit = chroma samples may leave the f32 colour range (Asum >= 249)
+                    const uint32_t Eb = ((__float_as_uint(E) + 1u) & ~1u) | ((cur_chroma && !(Asum < 249.0f)) ? 1u : 0u);
+                    const float Ef = __uint_as_float(Eb);
+                    a.ebound[gb] = !(Asum < 4000.0f) ? __builtin_inff() : ((int)ncw < 0 ? Ef : -Ef);
                 }
-                F &= F_OVER | F_HEAD | F_HEAD_NONCORNER | F_INSIDE;
                 Asum = 0.0f;
                 nnz = 0;
+                ncw = 0;
             }
         }
         if (ebits & E_BAD) err |= 8;
         if (ebits & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
-        if (F & F_OVER) err |= 32;       // run past the end of a block
+        if (over & E_ACSYM) err |= 32;   // run past the end of a block
         // the reference keeps its DC predictors as ints (MCU.cpp:107-112); one that leaves int16 would wrap here
         // silently: outside the contract, reported instead
         if (dcrange >> 16) err |= KPEG_ERR_DC_RANGE;
-        head = (F & F_HEAD) != 0;
-        hcorner = !(F & F_HEAD_NONCORNER);
+        head = (fl & FL_HADHEAD) != 0;
+        hcorner = !(fl & FL_HNC);
         tail_gb = gb;
-        tail_chroma = tb >= 2 * LUT_BYTES ? 1 : 0;
-        if (k != 0 && (F & F_INSIDE))
-            share = make_int4(__float_as_int(Asum), nnz, SH_OPEN | ((F & F_NONCORNER) ? 0 : SH_CORNER) | ((F & F_STARTED) ? SH_STARTED : 0), 0);
+        tail_chroma = (int)cur_chroma;
+        if (k != 0 && pend != 0)   // (pend == 0: the lane did nothing, or the segment's last block ended here -- then k == 0)
+            share = make_int4(__float_as_int(Asum), nnz, SH_OPEN | ((int)ncw < 0 ? 0 : SH_CORNER) | ((fl & FL_INHEAD) ? 0 : SH_STARTED), 0);
         // end of the last tile: by the lane in which the stream's last block ended (bits after it are ignored, as the
         // reference ignores them: a later lane never gets here)
-        if (COMPACT && last_block_ended_here && g.seg + 1 == nseg) a.tile_start[a.ntiles] = ord;
+        if (COMPACT && (fl & FL_LAST) && g.seg + 1 == nseg) a.tile_start[a.ntiles] = ord;
         // the last sub-sequence of a segment must have produced the segment's last block, all of it
         if (g.li + 1 == a.sub_base[g.seg + 1] - first) {
             if (b < blk_limit) err |= 128;
-            if (k != 0 && (F & F_INSIDE)) err |= 64;   // (bits after the segment's last block are ignored, as the reference ignores them)
+            if (k != 0 && b >= 1 && b - 1 < blk_limit) err |= 64;   // (bits after the segment's last block are ignored, as the reference ignores them)
         }
     }
 #if KPEG_SYNC_STATS
