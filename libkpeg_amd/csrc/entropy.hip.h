@@ -224,7 +224,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
 //    is running or done, and bounds the wait in time (s_memrealtime ticks, 100 MHz): on expiry it sets
 //    KPEG_ERR_TIMEOUT in the status word and goes on with what it has, so that kpeg_hip_sync() returns
 //    KPEG_HIP_E_DEVICE instead of the queue hanging.
-constexpr unsigned long long K0_SPIN_TICKS = 50000ull;        // 0.5 ms (a predecessor's 4 KiB take microseconds), then the fallback
+constexpr unsigned long long K0_SPIN_TICKS = 50000ull;        // 0.5 ms (a predecessor's 8 KiB take microseconds), then the fallback
 constexpr unsigned long long K1_SPIN_TICKS = 2000000000ull;   // 20 s: a predecessor's wait includes the whole chain before it
 struct SpinGuard {
     unsigned long long t0 = 0, limit;
@@ -249,7 +249,7 @@ __device__ unsigned long long g_ent_stamp[2][8192 * 16];
 
 struct EntropyScratch {
     void* d_u = nullptr;        size_t u_cap = 0;       // un-stuffed words
-    void* d_part = nullptr;     size_t part_cap = 0;    // K0's look-back words, one per 4 KiB of scan
+    void* d_part = nullptr;     size_t part_cap = 0;    // K0's look-back words, one per 8 KiB of scan
     bool part_clean = false;    // d_part is all zero (the previous call's last K1 launch cleared what that call used)
     void* d_segoff = nullptr;   size_t seg_cap = 0;     // seg_off[S+1], sub_base[S+1]
     void* d_state = nullptr;    size_t state_cap = 0;   // X[nsub], Xb[2][nwg], assumed[nwg] uint64
@@ -308,7 +308,10 @@ struct EntropyLaunch {
 // (byteStuffScanData's `i + 8 < size - 8`, Decoder.cpp:637).  With restart markers: drop every
 // stuffed 00 and both bytes of FF D0..D7.
 constexpr int US_BYTES_PER_THREAD = 16;
-constexpr int US_THREADS = 256;
+#ifndef KPEG_US_THREADS
+#define KPEG_US_THREADS 512   // 8 KiB of scan per workgroup (256 / 512 / 1024 threads: K0 23.5 / 21.1 / 24.9 us on the 8K image)
+#endif
+constexpr int US_THREADS = KPEG_US_THREADS;
 constexpr int US_BLOCK_BYTES = US_BYTES_PER_THREAD * US_THREADS;
 
 // keep / marker flags of one thread's 16 bytes, held in w[0..3] (little-endian), prev = the byte before them,
@@ -341,7 +344,7 @@ __device__ __forceinline__ void us_flags(const uint32_t w[4], uint32_t prev, uin
     }
 }
 
-// One launch: every workgroup flags its 4 KiB (one 16-byte load per thread), scans its keep/marker counts,
+// One launch: every workgroup flags its 8 KiB (one 16-byte load per thread), scans its keep/marker counts,
 // gets its base from its predecessors by decoupled look-back (aggregate / inclusive prefix published in one
 // 64-bit word: kept bytes [27:0], markers [54:28], state [63:62]; workgroups are dispatched in index order),
 // compacts its kept bytes in LDS in their final word order and writes them out as whole words.  The last
@@ -442,7 +445,7 @@ __device__ __forceinline__ void us_locate(const UnstuffBatch& bt, uint32_t g, co
     }
 }
 
-// Look-back fallback: (kept bytes, markers) of workgroup j's 4 KiB, computed by one wavefront from the input bytes --
+// Look-back fallback: (kept bytes, markers) of workgroup j's 8 KiB, computed by one wavefront from the input bytes --
 // what workgroup j publishes as its aggregate.  Called with the whole wavefront converged.
 __device__ __forceinline__ unsigned long long us_aggregate_wave(const UnstuffBatch& bt, uint32_t j, const uint8_t* b, uint32_t n, bool rst)
 {

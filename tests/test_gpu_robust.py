@@ -59,7 +59,7 @@ def test_k0_look_back_falls_back_when_a_predecessor_never_publishes(ctx):
     successors must not wait for it: after a short bound they compute its aggregate from its input bytes themselves
     (look-back with fallback) -- the decode is correct and nothing hangs, whatever the dispatch order."""
     frame, scan, want = _case()
-    assert scan.size > 3 * 4096   # several K0 workgroups
+    assert scan.size > 3 * 8192   # several K0 workgroups (8 KiB of scan each)
     assert ctx.lib.kpeg_hip_debug_set(ctx._h, 6, 1) == 0
     try:
         for bound_us in (0, 200):   # the default bound and a longer one
@@ -90,7 +90,7 @@ def test_k0_look_back_fallback_on_every_kind_of_chunk(ctx):
             else:
                 st, want = T.oracle_decode(data)
                 p = T.oracle_parse(data)
-            assert len(p.scan) > 5 * 4096
+            assert len(p.scan) > 5 * 8192
             got = ctx.decode_scan(T.make_frame(p, interval), p.scan)
             assert np.array_equal(got, want), (w, h, interval)
         frames, scans, wants = None, [], []
