@@ -888,12 +888,22 @@ struct SubGeom {
     uint32_t seg, li;      // segment and index inside it
     uint32_t pstart, pend; // bit range of the sub-sequence
 };
+// n_u: the un-stuffed length (meta->n_u).  One segment (a stream without restart markers) needs none of the tables:
+// seg_off = {0, n_u}, sub_base = {0, ...} -- and no load that waits for another.
 template <int S>
 __device__ __forceinline__ SubGeom sub_geom(const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ sub_base,
-                                            uint32_t nseg, uint32_t i)
+                                            uint32_t nseg, uint32_t n_u, uint32_t i)
 {
     KPEG_GEOMETRY(S);
     SubGeom g;
+    if (nseg == 1) {
+        g.seg = 0;
+        g.li = i;
+        const uint32_t s1 = n_u * 8;
+        g.pstart = min(i * SUBSEQ_BITS, s1);
+        g.pend = min(i * SUBSEQ_BITS + SUBSEQ_BITS, s1);
+        return g;
+    }
     g.seg = nseg > 1 ? locate_segment(sub_base, nseg, i) : 0;
     g.li = i - sub_base[g.seg];
     uint32_t s0 = seg_off[g.seg] * 8, s1 = seg_off[g.seg + 1] * 8;
@@ -1049,7 +1059,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     const int p = a.pass;
     uint32_t g = blockIdx.x;
     const uint32_t t = threadIdx.x;
-    const uint32_t nsub = a.meta->nsub;
+    const uint32_t nsub = a.meta->nsub, nseg = a.meta->nseg, n_u = a.meta->n_u;   // (one scalar load: the fields are neighbours)
     // The last launch (chained) also scans the workgroup totals: at once by workgroup 0 if the pass
     // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
     const bool rippling = p >= 2 && a.meta->moved[p - 1] != 0;
@@ -1120,14 +1130,13 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     const uint64_t tm0 = __builtin_amdgcn_s_memtime();
 #endif
     load_tables(&T, a.tabs);
-    const uint32_t nseg = a.meta->nseg;
     const uint32_t nown = min((uint32_t)OWN, nsub - i0);
     const uint32_t wu = p == 0 ? min(a.warm, i0) : 0u;
     const uint32_t ibase = i0 - wu, nit = wu + nown;
     // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
-    const uint32_t w0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase).pstart >> 5;
+    const uint32_t w0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase).pstart >> 5;
     {
-        const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
+        const uint32_t total_words = (n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
     __syncthreads();
@@ -1154,7 +1163,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
     const uint64_t tm1 = __builtin_amdgcn_s_memtime();
 #endif
     if (have) {
-        const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, ibase + t);
+        const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase + t);
         pend = geo.pend;
         segfirst = geo.li == 0;
         fixed = segfirst || (p == 0 && t == 0);
@@ -1409,9 +1418,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     __shared__ int4 s_pre[SYNC_WG];   // first the scan of cnt, then every lane's share of the block open at its exit
     __shared__ uint32_t s_prer[COMPACT ? SYNC_WG : 1];   // scan of the record counts
     __shared__ int4 s_wred[SYNC_WG / 64];
+    __shared__ uint32_t s_wredr[COMPACT ? SYNC_WG / 64 : 1];
     constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
-    const uint32_t nsub = a.meta->nsub;
+    const uint32_t nsub = a.meta->nsub, nseg = a.meta->nseg, n_u = a.meta->n_u;
     const uint32_t i0 = blockIdx.x * OWN;
     if (i0 >= nsub) return;
 #if KPEG_SYNC_STATS
@@ -1421,40 +1431,47 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     load_tables(&T, a.tabs);
     const uint32_t i = i0 + threadIdx.x;
     const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
-    const uint32_t nseg = a.meta->nseg;
-    const SubGeom g0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, i0);
+    const SubGeom g0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i0);
     const uint32_t w0 = g0.pstart >> 5;
     {
-        const uint32_t total_words = (a.meta->n_u + 3) / 4 + 2;
+        const uint32_t total_words = (n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
 #if KPEG_SYNC_STATS
     __syncthreads();
     const uint64_t tw1 = __builtin_amdgcn_s_memtime();
 #endif
-    // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup ...
+    // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup (inside the wavefronts by
+    // shuffles, their totals through LDS: one barrier instead of the twenty of a scan that lives in LDS) ...
     {
-        int4 v = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
+        const int4 v = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
         const uint32_t vr = COMPACT && valid ? a.nrec[i] : 0u;
-        s_pre[threadIdx.x] = v;
-        if (COMPACT) s_prer[threadIdx.x] = vr;
-        __syncthreads();
-        for (int o = 1; o < SYNC_WG; o <<= 1) {
-            int4 t = make_int4(0, 0, 0, 0);
-            uint32_t tr = 0;
-            if ((int)threadIdx.x >= o) {
-                t = s_pre[threadIdx.x - o];
-                if (COMPACT) tr = s_prer[threadIdx.x - o];
+        int4 inc = v;
+        uint32_t incr = vr;
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(inc.x, o), y = __shfl_up(inc.y, o), z = __shfl_up(inc.z, o), w = __shfl_up(inc.w, o);
+            const uint32_t r = COMPACT ? (uint32_t)__shfl_up((int)incr, o) : 0u;
+            if ((int)lane >= o) {
+                inc = make_int4(inc.x + x, inc.y + y, inc.z + z, inc.w + w);
+                incr += r;
             }
-            __syncthreads();
-            s_pre[threadIdx.x] = add4(s_pre[threadIdx.x], t);
-            if (COMPACT) s_prer[threadIdx.x] += tr;
-            __syncthreads();
         }
-        const int4 incl = s_pre[threadIdx.x];
+        if (lane == 63) {
+            s_wred[wave] = inc;
+            if (COMPACT) s_wredr[wave] = incr;
+        }
         __syncthreads();
-        s_pre[threadIdx.x] = make_int4(incl.x - v.x, incl.y - v.y, incl.z - v.z, incl.w - v.w);
-        if (COMPACT) s_prer[threadIdx.x] -= vr;   // exclusive
+        int4 base = make_int4(0, 0, 0, 0);
+        uint32_t baser = 0;
+        for (uint32_t q = 0; q < SYNC_WG / 64; ++q)
+            if (q < wave) {
+                base = add4(base, s_wred[q]);
+                if (COMPACT) baser += s_wredr[q];
+            }
+        s_pre[threadIdx.x] = make_int4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
+        if (COMPACT) s_prer[threadIdx.x] = baser + incr - vr;   // exclusive
+        __syncthreads();   // (s_wred is used again below)
     }
     // ... + the workgroup's offset, counted from the start of the restart segment.  A segment that began in
     // this workgroup re-bases on a neighbour's scan value; the one open at the workgroup's first
@@ -1495,7 +1512,7 @@ __global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
     constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
     int4 pre = make_int4(0, 0, 0, 0);
     if (valid) {
-        const SubGeom g = sub_geom<S>(a.seg_off, a.sub_base, nseg, i);
+        const SubGeom g = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i);
         DecState s;
         if (g.li == 0) {
             s.p = g.pstart;
