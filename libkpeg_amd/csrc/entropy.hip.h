@@ -971,58 +971,67 @@ __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_
                           uint32_t nparts, int4* s, int4* carry)
 {
     KPEG_GEOMETRY(S);
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (uint32_t i = t; i < nparts; i += SYNC_WG) part[i] = 0ull;
     const uint32_t nw = (meta->nsub + OWN - 1) / OWN;
-    if (t == 0) *carry = make_int4(0, 0, 0, 0);
-    __syncthreads();
+    // s[0 .. SYNC_WG / 64): the wavefronts' totals; s[SYNC_WG / 64 ..): the same for the record counts (their .x)
+    uint32_t* rc = reinterpret_cast<uint32_t*>(carry) + 1;   // (carry->x is read below: a word beside it)
+    int4 run = make_int4(0, 0, 0, 0);     // totals of the chunks before this one (every thread keeps its own copy)
+    uint32_t runr = 0;
     for (uint32_t base = 0; base < nw; base += SYNC_WG) {
         const uint32_t i = base + t;
         int4 v = make_int4(0, 0, 0, 0);
+        uint32_t vr = 0;
         if (i < nw) {
             // written by other workgroups of this launch: read past this CU's L1
             int* w = reinterpret_cast<int*>(wsum + i);
             v = make_int4(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                           __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(w + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (COUNT) vr = __hip_atomic_load(&wrec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s[t] = v;
-        __syncthreads();
-        for (int o = 1; o < SYNC_WG; o <<= 1) {
-            int4 x = make_int4(0, 0, 0, 0);
-            if ((int)t >= o) x = s[t - o];
-            __syncthreads();
-            s[t] = add4(s[t], x);
-            __syncthreads();
+        // inclusive scan inside the wavefront by shuffles, the wavefronts' totals through LDS
+        int4 inc = v;
+        uint32_t incr = vr;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(inc.x, o), y = __shfl_up(inc.y, o), z = __shfl_up(inc.z, o), w = __shfl_up(inc.w, o);
+            const uint32_t r = COUNT ? (uint32_t)__shfl_up((int)incr, o) : 0u;
+            if ((int)lane >= o) {
+                inc = make_int4(inc.x + x, inc.y + y, inc.z + z, inc.w + w);
+                incr += r;
+            }
         }
-        const int4 incl = s[t], c = *carry;
-        if (i < nw) wsum[i] = make_int4(c.x + incl.x - v.x, c.y + incl.y - v.y, c.z + incl.z - v.z, c.w + incl.w - v.w);
+        __syncthreads();   // (the totals of the chunk before have been read)
+        if (lane == 63) {
+            s[wave] = inc;
+            if (COUNT) s[SYNC_WG / 64 + wave].x = (int)incr;
+        }
         __syncthreads();
-        if (t == SYNC_WG - 1) *carry = add4(c, incl);
-        __syncthreads();
+        int4 b = run;
+        uint32_t br = runr;
+        int4 tot = run;
+        uint32_t totr = runr;
+        for (uint32_t q = 0; q < SYNC_WG / 64; ++q) {
+            const int4 wq = s[q];
+            const uint32_t rq = COUNT ? (uint32_t)s[SYNC_WG / 64 + q].x : 0u;
+            if (q < wave) {
+                b = add4(b, wq);
+                br += rq;
+            }
+            tot = add4(tot, wq);
+            totr += rq;
+        }
+        if (i < nw) {
+            wsum[i] = make_int4(b.x + inc.x - v.x, b.y + inc.y - v.y, b.z + inc.z - v.z, b.w + inc.w - v.w);   // exclusive
+            if (COUNT) wrec[i] = br + incr - vr;
+        }
+        run = tot;
+        runr = totr;
     }
-    // the same for the record counts (one component: the int4 slots' first lanes)
-    uint32_t* sr = reinterpret_cast<uint32_t*>(s);
-    uint32_t* rc = reinterpret_cast<uint32_t*>(carry) + 1;   // (carry->x is read below: a word beside it)
-    if (t == 0) *rc = 0;
+    if (t == 0) {
+        *carry = run;
+        *rc = runr;
+    }
     __syncthreads();
-    for (uint32_t base = 0; COUNT && base < nw; base += SYNC_WG) {
-        const uint32_t i = base + t;
-        const uint32_t v = i < nw ? __hip_atomic_load(&wrec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        sr[t] = v;
-        __syncthreads();
-        for (int o = 1; o < SYNC_WG; o <<= 1) {
-            uint32_t x = 0;
-            if ((int)t >= o) x = sr[t - o];
-            __syncthreads();
-            sr[t] += x;
-            __syncthreads();
-        }
-        const uint32_t incl = sr[t], c = *rc;
-        if (i < nw) wrec[i] = c + incl - v;
-        __syncthreads();
-        if (t == SYNC_WG - 1) *rc = c + incl;
-        __syncthreads();
-    }
     if (t == 0) {
         meta->total_rec = *rc;
         meta->total_blocks = (uint32_t)carry->x;
@@ -1042,8 +1051,10 @@ __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_
 //   the stream needs more than WARM_BITS to re-synchronise.
 // Pass p >= 1: a workgroup whose assumed entry state differs from its predecessor's real exit
 //   state re-decodes from that state and the change ripples on.
+// (6 waves per SIMD = 3 workgroups per CU: all of an 8K image's workgroups run at once; the scan code at the kernel's end
+// must not be allowed to raise the register count past that)
 template <int S, bool COUNT>
-__global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
+__global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sync_pass(SyncArgs a)
 {
     KPEG_GEOMETRY(S);
     __shared__ __attribute__((aligned(16))) LdsTables T;
@@ -1340,10 +1351,10 @@ __global__ __launch_bounds__(SYNC_WG) void k_sync_pass(SyncArgs a)
             w = add4(w, s_red[q]);
             wr += s_redn[q];
         }
-        a.wsum[g] = w;
-        a.wrec[g] = wr;
         const uint64_t last = s_edge[1];
         const bool known = s_edge[0] == X_NONE;   // first own sub-sequence opens a restart segment
+        a.wsum[g] = w;
+        a.wrec[g] = wr;
         a.assumed[g] = s_edge[0];
         Xb_cur[g] = last;
         if (a.chained && !mute) {
@@ -1411,7 +1422,7 @@ constexpr uint32_t TILE_BLOCKS = 24;   // K4's tile: 8 MCUs x 3 components
 // finds the other's sum there settles the bound.  Bounds are preset to +inf (K4's exact path), so a
 // block nobody settles (corrupt stream) is still decoded correctly.
 template <int S, bool COMPACT>
-__global__ __launch_bounds__(SYNC_WG) void k_write(WriteArgs a)
+__global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_write(WriteArgs a)
 {
     KPEG_GEOMETRY(S);
     __shared__ __attribute__((aligned(16))) LdsTables T;
