@@ -508,11 +508,11 @@ static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t 
     if ((f->width / 8) % TILE_MCUS != 0) return false;
     const bool dense = ctx->subseq ? ctx->subseq >= SUBSEQ_DENSE : scan_bytes * 8 >= nmcu * 64 * 4;   // entropy_decode_launch's rule
     if (ctx->coef_layout == 2) return true;
-    // Measured end to end (tools/layout_sizes.sh, round 2): 1920x1080 (12 MiB of dense coefficients) 96 us dense against 101
-    // compact, 3840x2160 (48 MiB) 119 / 118, 7680x4320 (190 MiB) 232 / 215, 16384x16384 2.05 / 1.56 ms, 256 x 1080p 141 -> 198
+    // Measured end to end (tools/layout_sizes.sh, round 2, us dense / compact): 1920x1080 (12 MiB of dense coefficients)
+    // 91 / 93, 3840x2160 (48 MiB) 111 / 108, 7680x4320 (190 MiB) 220 / 199, 16384x16384 2050 / 1270, 256 x 1080p 141 -> 207
     // Gpixel/s: the dense layout's 2-byte scatter and its clear cost K2 and K1 more than the rebuild in LDS costs K4 once the
     // image is large enough for those to show beside the kernels' fixed latencies.
-    return !dense && nmcu * 384 > ((uint64_t)64 << 20);
+    return !dense && nmcu * 384 > ((uint64_t)32 << 20);
 }
 
 static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint32_t nmcu,
