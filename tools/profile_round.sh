@@ -11,7 +11,7 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json
 python3 bench.py --side-figures --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_side_figures.json
 python3 bench.py --batch 256 --steps 5 --warmup 2 2>/dev/null | tail -1 > $out/bench_batch256.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --no-cpu-baseline > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --no-cpu-baseline --steps 40 --warmup 3 > $out/stats.log 2>&1
 f=$(ls $out/stats/*kernel_stats.csv $out/stats/*/*kernel_stats.csv 2>/dev/null | head -1)
 cp "$f" $out/kernel_stats.csv
 rm -rf $out/stats
