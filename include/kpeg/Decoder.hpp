@@ -66,6 +66,10 @@ namespace kpeg
             /// it reads past its MCU vector.  Here all MCUs of the padded picture are decoded and the picture is cropped
             /// the way Image::createImageFromMCUs crops it.
             void setAnySizeSupport( bool on ) { allowAnySize_ = on; }
+            /// Extension, off by default: accept 4:2:0 files (luma sampled 2x2, any size).  The reference answers TERMINATE on
+            /// every sampling factor other than 1x1 (src/Decoder.cpp:339-356).  Decoded through the reference's own per-block
+            /// arithmetic, every chroma sample repeated over its 2x2 luma samples.
+            void set420Support( bool on ) { allow420_ = on; }
             /// Parse only: stop at the seam and leave the tables for frameInfo().
             void setParseOnly( bool on ) { parseOnly_ = on; }
             /// Tables and geometry as handed to the GPU path; valid after decodeImageFile().
@@ -114,6 +118,8 @@ namespace kpeg
             bool allowDRI_, parseOnly_;
             bool allowGray_ = false;
             bool allowAnySize_ = false;
+            bool allow420_ = false;
+            bool sub420_ = false;
             int components_ = 3;
     };
 }

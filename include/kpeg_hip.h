@@ -47,6 +47,8 @@ typedef struct kpeg_hip_ctx kpeg_hip_ctx;
 
 /* kpeg::HuffmanTable (include/Types.hpp:116) flattened: counts[i] codes of length i+1,
  * symbols in code order. */
+#define KPEG_FRAME_420 0x0203u /* kpeg_frame.components: three components, luma sampled 2x2 */
+
 typedef struct kpeg_dht {
     uint8_t counts[16];
     uint8_t symbols[256];
@@ -65,7 +67,11 @@ typedef struct kpeg_frame {
     uint32_t components;        /* 0 or 3 = Y Cb Cr 4:4:4, what the reference decodes; 1 = grayscale (extension, off by
                                    default in the host parser: the reference reads three component triples whatever
                                    SOF0 says, src/Decoder.cpp:339, and fails on such files): one block per MCU decoded with
-                                   table id 0 through the same per-block arithmetic, R = G = B = clamp(Y)                */
+                                   table id 0 through the same per-block arithmetic, R = G = B = clamp(Y);
+                                   KPEG_FRAME_420 = Y Cb Cr 4:2:0 (extension, off by default in the host parser: the
+                                   reference answers TERMINATE on sampling factors other than 1x1): 16x16 MCUs of six
+                                   blocks through the same per-block arithmetic, every chroma sample repeated 2x2;
+                                   whole-image entry points only, any width / height                                    */
 } kpeg_frame;
 
 /* Per-call device timings (milliseconds, HIP events on the context's stream), valid after

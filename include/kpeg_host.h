@@ -19,6 +19,7 @@ extern "C" {
 
 #define KPEG_PARSE_ALLOW_DRI 1u /* extension: accept DRI/RSTn (the reference rejects them) */
 #define KPEG_PARSE_ALLOW_GRAY 2u /* extension: accept one-component (grayscale) baseline files (the reference fails on them) */
+#define KPEG_PARSE_ALLOW_420 8u /* extension: accept 4:2:0 files, any size (the reference answers TERMINATE on subsampled files) */
 #define KPEG_PARSE_ALLOW_ANY_SIZE 4u /* extension: accept widths / heights that are not multiples of 8 (the reference reads past its MCU vector on them) */
 
 /* Returns the reference's JPEGDecoder::ResultCode (0 SUCCESS, 1 TERMINATE, 2 ERROR,

@@ -265,6 +265,8 @@ def decode_sharded(ctxs, frame, scan, d_rgb_root=None):
 PARSE_ALLOW_DRI = 1
 PARSE_ALLOW_GRAY = 2
 PARSE_ALLOW_ANY_SIZE = 4
+PARSE_ALLOW_420 = 8
+FRAME_420 = 0x203
 SUCCESS, TERMINATE, ERROR, DECODE_INCOMPLETE, DECODE_DONE = 0, 1, 2, 3, 4
 _host = None
 
@@ -286,7 +288,7 @@ def load_host():
     return H
 
 
-def host_parse(data, allow_dri=False, allow_gray=False, allow_any_size=False):
+def host_parse(data, allow_dri=False, allow_gray=False, allow_any_size=False, allow_420=False):
     """Run the product's marker parser on an in-memory JFIF file.
     Returns (result_code, Frame or None, scan bytes (numpy uint8) or None)."""
     H = load_host()
@@ -294,7 +296,7 @@ def host_parse(data, allow_dri=False, allow_gray=False, allow_any_size=False):
     frame = Frame()
     scan = np.empty(buf.size + 1, np.uint8)
     n = ctypes.c_size_t(0)
-    rc = H.kpeg_host_parse(buf.ctypes.data, buf.size, (PARSE_ALLOW_DRI if allow_dri else 0) | (PARSE_ALLOW_GRAY if allow_gray else 0) | (PARSE_ALLOW_ANY_SIZE if allow_any_size else 0),
+    rc = H.kpeg_host_parse(buf.ctypes.data, buf.size, (PARSE_ALLOW_DRI if allow_dri else 0) | (PARSE_ALLOW_GRAY if allow_gray else 0) | (PARSE_ALLOW_ANY_SIZE if allow_any_size else 0) | (PARSE_ALLOW_420 if allow_420 else 0),
                            ctypes.byref(frame),
                            scan.ctypes.data, scan.size, ctypes.byref(n))
     if rc != DECODE_DONE:

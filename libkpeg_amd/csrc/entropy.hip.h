@@ -292,6 +292,7 @@ struct EntropyLaunch {
     unsigned long long spin_ticks = 0;   // bound of the waits between workgroups in 100 MHz ticks, 0 = defaults (test hook)
     uint32_t fault = 0;                  // fault injection (test hook): bit 0 K0's, bit 1 K1's workgroup 0 never publishes
     uint32_t gray = 0;                   // one-component stream (kpeg_frame::components == 1)
+    uint32_t sub420 = 0;                 // 4:2:0 (extension, dense layout): nmcu counts 16x16 MCUs of six blocks
     // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
     // from the known state, DC predictors reset): d_scan / scan_len are unused, restart_interval = MCUs per image
     uint32_t nimg = 0;
@@ -657,21 +658,21 @@ __global__ __launch_bounds__(US_THREADS) void k_unstuff(const uint8_t* b, uint32
 
 struct DecState {   // at a codeword boundary
     uint32_t p;     // bit position in the un-stuffed string
-    uint32_t c;     // component 0..2 of the block being decoded
+    uint32_t c;     // component 0..2 of the block being decoded (4:2:0: block 0..5 of the MCU, Y Y Y Y Cb Cr)
     uint32_t k;     // 0: next symbol is the DC symbol; 1..63: AC, k-1 coefficients placed so far
     uint32_t q;     // k != 0: 1 if the block in progress keeps its AC terms (its DC symbol was not 0x00, quirk Q1); else 0
 };
 __device__ __forceinline__ uint64_t pack_state(const DecState& s)
 {
-    return (uint64_t)s.p | ((uint64_t)s.c << 32) | ((uint64_t)s.k << 34) | ((uint64_t)s.q << 41);
+    return (uint64_t)s.p | ((uint64_t)s.c << 32) | ((uint64_t)s.k << 35) | ((uint64_t)s.q << 42);
 }
 __device__ __forceinline__ DecState unpack_state(uint64_t v)
 {
     DecState s;
     s.p = (uint32_t)v;
-    s.c = (uint32_t)(v >> 32) & 3;
-    s.k = (uint32_t)(v >> 34) & 127;
-    s.q = (uint32_t)(v >> 41) & 1;
+    s.c = (uint32_t)(v >> 32) & 7;
+    s.k = (uint32_t)(v >> 35) & 127;
+    s.q = (uint32_t)(v >> 42) & 1;
     return s;
 }
 
@@ -811,10 +812,17 @@ struct RunResult {
 // gray (wave-uniform): one component -- the table sequence is DC0 AC0 and every block adds to the one DC sum.
 // SUMS = false: only the exit state is wanted (the first decode of K1, from a guessed entry state: whatever it counts is
 // thrown away with the guess) -- the DC symbols then cost no more than any other.
-template <bool COUNT, bool SUMS = true>
+// S420 (extension, dense layout): MCUs of six blocks Y Y Y Y Cb Cr.  tb then counts twelve VIRTUAL table slots (DC AC per
+// block); the six tables in LDS serve them (phys_table), and the DC sums are kept per component instead of rotating.
+template <bool S420>
+__device__ __forceinline__ uint32_t phys_table(uint32_t tb)
+{
+    return S420 ? ((tb & LUT_BYTES) | (tb >= 8 * LUT_BYTES ? 2 * LUT_BYTES : 0u)) : tb;
+}
+template <bool COUNT, bool SUMS = true, bool S420 = false>
 __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend, bool gray)
 {
-    const uint32_t tb_wrap = gray ? 2 * LUT_BYTES : 6 * LUT_BYTES;
+    const uint32_t tb_wrap = S420 ? 12 * LUT_BYTES : (gray ? 2 * LUT_BYTES : 6 * LUT_BYTES);
     BitReader br;
     br.init(bits, w0, s.p);
     uint32_t p = s.p, k = s.k, q = s.q, tb = state_table(s);
@@ -825,10 +833,11 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
 #if KPEG_SYNC_STATS
     uint32_t iters = 0;
 #endif
-    uint32_t e1 = lut_first(T, tb, br.peek());
+    uint32_t e1 = lut_first(T, phys_table<S420>(tb), br.peek());
     while (p < pend) {
         const uint32_t win = br.peek();
-        const uint32_t e = lut_finish(T, tb, win, e1);
+        const uint32_t tbo = tb;
+        const uint32_t e = lut_finish(T, phys_table<S420>(tb), win, e1);
         const uint32_t kraw = k + ((e >> 16) & 127);
         const bool adv = kraw >= 64;   // this table's turn ends: DC symbol, EOB, 63rd coefficient (Decoder.cpp:759)
         // exactly K2's condition for storing an AC coefficient, minus its check that the block lies inside the segment
@@ -840,12 +849,19 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
         tb = tb == tb_wrap ? 0u : tb;
         p += e & 31;
         br.consume(e & 31);
-        e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way (one read too many at the end: harmless)
+        e1 = lut_first(T, phys_table<S420>(tb), br.peek());   // next symbol's entry on its way (one read too many at the end: harmless)
         if (SUMS && (e & E_ISDC)) {
-            const int n = s0 + extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
-            s0 = gray ? n : s1;
-            s1 = gray ? s1 : s2;
-            s2 = gray ? s2 : n;
+            const int d = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
+            if (S420) {
+                s0 += tbo < 8 * LUT_BYTES ? d : 0;
+                s1 += tbo == 8 * LUT_BYTES ? d : 0;
+                s2 += tbo == 10 * LUT_BYTES ? d : 0;
+            } else {
+                const int n = s0 + d;
+                s0 = gray ? n : s1;
+                s1 = gray ? s1 : s2;
+                s2 = gray ? s2 : n;
+            }
             nb++;
         }
 #if KPEG_SYNC_STATS
@@ -854,7 +870,7 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
     }
     RunResult r;
     // slot j holds component (cfirst + nb + j) mod 3
-    const uint32_t rot = gray ? 0u : (cfirst + nb) % 3;
+    const uint32_t rot = (gray || S420) ? 0u : (cfirst + nb) % 3;
     r.nrec = nrec;
     r.cnt.x = (int)nb;
     r.cnt.y = rot == 0 ? s0 : (rot == 1 ? s2 : s1);
@@ -1053,7 +1069,7 @@ __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_
 //   state re-decodes from that state and the change ripples on.
 // (6 waves per SIMD = 3 workgroups per CU: all of an 8K image's workgroups run at once; the scan code at the kernel's end
 // must not be allowed to raise the register count past that)
-template <int S, bool COUNT>
+template <int S, bool COUNT, bool S420 = false>
 __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sync_pass(SyncArgs a)
 {
     KPEG_GEOMETRY(S);
@@ -1185,7 +1201,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             s.k = 0;
             s.q = 0;
             used = pack_state(s);
-            r = run_count<COUNT, false>(T, s_bits, w0, s, pend, a.gray != 0);   // exit state only: see below
+            r = run_count<COUNT, false, S420>(T, s_bits, w0, s, pend, a.gray != 0);   // exit state only: see below
 #if KPEG_SYNC_STATS
             st_runs++;
             st_iters += r.iters;
@@ -1269,7 +1285,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
                 continue;
             }
             if (again) {
-                r = run_count<COUNT>(T, s_bits, w0, unpack_state(in), pend, a.gray != 0);
+                r = run_count<COUNT, true, S420>(T, s_bits, w0, unpack_state(in), pend, a.gray != 0);
                 used = in;
 #if KPEG_SYNC_STATS
                 st_runs++;
@@ -1421,7 +1437,7 @@ constexpr uint32_t TILE_BLOCKS = 24;   // K4's tile: 8 MCUs x 3 components
 // A block split over two workgroups: both sides swap their sum into an exchange slot, and the side that
 // finds the other's sum there settles the bound.  Bounds are preset to +inf (K4's exact path), so a
 // block nobody settles (corrupt stream) is still decoded correctly.
-template <int S, bool COMPACT>
+template <int S, bool COMPACT, bool S420 = false>
 __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_write(WriteArgs a)
 {
     KPEG_GEOMETRY(S);
@@ -1549,18 +1565,19 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         }
         const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
         const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
-        const bool gray = !COMPACT && a.gray != 0;     // one block per MCU, stored as the MCU's luma block (stride 3); dense layout only
+        const bool gray = !COMPACT && !S420 && a.gray != 0;     // one block per MCU, stored as the MCU's luma block (stride 3); dense layout only
         const uint32_t bstride = gray ? 3u : 1u;
-        const uint32_t blk_limit = gray ? seg_mcus : seg_mcus * 3;   // blocks of this segment
+        constexpr uint32_t BPM = S420 ? 6u : 3u;       // blocks per MCU (4:2:0, extension: Y Y Y Y Cb Cr)
+        const uint32_t blk_limit = gray ? seg_mcus : seg_mcus * BPM;   // blocks of this segment
         uint32_t b = (uint32_t)pre.x;                  // blocks started so far, within the segment
 
         BitReader br;
         br.init(s_bits, w0, s.p);
         uint32_t p = s.p, k = s.k, tb = state_table(s);
-        const uint32_t tb_wrap = gray ? 2 * LUT_BYTES : 6 * LUT_BYTES;
-        // DC predictors rotate with the blocks: pd0 belongs to the next block to start (component b % 3,
+        const uint32_t tb_wrap = S420 ? 12 * LUT_BYTES : (gray ? 2 * LUT_BYTES : 6 * LUT_BYTES);
+        // DC predictors rotate with the blocks (4:2:0: one per component, pd0 = Y, pd1 = Cb, pd2 = Cr): pd0 belongs to the next block to start (component b % 3,
         // == the component of the table in use on a valid stream); DCDiff[c] += zz[0] (MCU.cpp:107)
-        const uint32_t cb = gray ? 0u : b % 3;
+        const uint32_t cb = (gray || S420) ? 0u : b % 3;
         int pd0 = cb == 0 ? pre.y : (cb == 1 ? pre.z : pre.w);
         int pd1 = cb == 0 ? pre.z : (cb == 1 ? pre.w : pre.y);
         int pd2 = cb == 0 ? pre.w : (cb == 1 ? pre.y : pre.z);
@@ -1592,9 +1609,10 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         }
         float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
         int nnz = 0;
-        const uint32_t gbase = seg_mcu0 * 3;
+        const uint32_t gbase = seg_mcu0 * BPM;
         uint32_t gb = gbase + (b ? b - 1 : 0) * bstride;          // block in progress
-        uint32_t cur_chroma = tb >= 2 * LUT_BYTES ? 1u : 0u;      // ... and whether it is a chroma block
+        constexpr uint32_t CHROMA_TB = S420 ? 8 * LUT_BYTES : 2 * LUT_BYTES;   // the first chroma table slot
+        uint32_t cur_chroma = tb >= CHROMA_TB ? 1u : 0u;          // ... and whether it is a chroma block
         // What this lane may touch: a corrupt stream can count more blocks than the segment has.  No block beyond the
         // segment's last is ever started (the loop ends with the block that completes the segment), so only the block in
         // progress at entry can lie outside: such a lane does nothing.
@@ -1606,10 +1624,11 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             fl = 0;
         }
         const float m00_l = T.zzm[0][0].x, m00_c = T.zzm[1][0].x;
-        uint32_t e1 = lut_first(T, tb, br.peek());
+        uint32_t e1 = lut_first(T, phys_table<S420>(tb), br.peek());
         while (p < pend) {
             const uint32_t win = br.peek();
-            const uint32_t e = lut_finish(T, tb, win, e1);
+            const uint32_t tbo = tb;
+            const uint32_t e = lut_finish(T, phys_table<S420>(tb), win, e1);
 #if KPEG_SYNC_STATS
             st_steps++;
 #endif
@@ -1618,21 +1637,29 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             const uint32_t kraw = k + ((e >> 16) & 127);
             const bool adv = kraw >= 64;
             const bool isdc = (e & E_ISDC) != 0;
-            const bool chroma = tb >= 2 * LUT_BYTES;              // the table in use: chroma tables
+            const bool chroma = tb >= CHROMA_TB;                  // the table in use: chroma tables
             k = adv ? ((e >> 14) & 1u) : kraw;
             tb += adv ? LUT_BYTES : 0u;
             tb = tb == tb_wrap ? 0u : tb;
-            e1 = lut_first(T, tb, br.peek());   // next symbol's entry on its way
+            e1 = lut_first(T, phys_table<S420>(tb), br.peek());   // next symbol's entry on its way
             const int ext = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
             ebits |= e;
             over |= kraw > 64 ? e : 0u;
             if (isdc) {
                 // a DC symbol opens block gbase + b; its value is coefficient 0 (DC predictors: DCDiff[c] += zz[0], MCU.cpp:107)
-                const int n = pd0 + ext;
+                int n;
+                if (S420) {
+                    n = (tbo < 8 * LUT_BYTES ? pd0 : (tbo == 8 * LUT_BYTES ? pd1 : pd2)) + ext;
+                    pd0 = tbo < 8 * LUT_BYTES ? n : pd0;
+                    pd1 = tbo == 8 * LUT_BYTES ? n : pd1;
+                    pd2 = tbo == 10 * LUT_BYTES ? n : pd2;
+                } else {
+                    n = pd0 + ext;
+                    pd0 = gray ? n : pd1;
+                    pd1 = gray ? pd1 : pd2;
+                    pd2 = gray ? pd2 : n;
+                }
                 dcrange |= (uint32_t)(n + 32768);   // bits above 15: the absolute DC does not fit the int16 coefficient layout
-                pd0 = gray ? n : pd1;
-                pd1 = gray ? pd1 : pd2;
-                pd2 = gray ? pd2 : n;
                 gb = gbase + b * bstride;
                 b++;
                 cur_chroma = chroma ? 1u : 0u;
@@ -1905,9 +1932,9 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.tile_start = L.d_tile_start;
     sa.ntiles = L.ntiles;
     sa.coef16 = (uint4*)L.d_coef;
-    sa.coef_n16 = (uint64_t)L.nmcu * 24;   // 384 bytes per MCU
+    sa.coef_n16 = (uint64_t)L.nmcu * (L.sub420 ? 48 : 24);   // 384 bytes per MCU (4:2:0: 768)
     sa.ebound = (uint32_t*)L.d_ebound;
-    sa.nblocks = L.nmcu * 3;
+    sa.nblocks = L.nmcu * (L.sub420 ? 6 : 3);
     sa.bslot = bslot;
     sa.done = done;
     sa.warm = L.warm < 0 ? (uint32_t)WARM : min((uint32_t)L.warm, (uint32_t)WARM);
@@ -1922,7 +1949,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     for (int t = 0; t < npass; ++t) {
         sa.pass = t;
         sa.chained = t == npass - 1 ? 1 : 0;
-        if (L.d_tile_start) hipLaunchKernelGGL((k_sync_pass<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        if (L.sub420) hipLaunchKernelGGL((k_sync_pass<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        else if (L.d_tile_start) hipLaunchKernelGGL((k_sync_pass<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
         else hipLaunchKernelGGL((k_sync_pass<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
     }
     mark(2);
@@ -1953,7 +1981,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     wa.tile_start = L.d_tile_start;
     wa.ntiles = L.ntiles;
     wa.gray = L.gray;
-    if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
+    if (L.sub420) hipLaunchKernelGGL((k_write<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
+    else if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else hipLaunchKernelGGL((k_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);
     mark(5);
@@ -1970,7 +1999,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
                                  std::string* err)
 {
     const uint64_t bytes = L.nimg ? L.total_len : (uint64_t)L.scan_len;
-    const bool dense = L.subseq ? L.subseq >= SUBSEQ_DENSE : bytes * 8 >= (uint64_t)L.nmcu * 64 * 4;   // from 4 bits per pixel
+    const bool dense = L.subseq ? L.subseq >= SUBSEQ_DENSE : bytes * 8 >= (uint64_t)L.nmcu * (L.sub420 ? 256 : 64) * 4;   // from 4 bits per pixel
     return dense ? entropy_decode_launch_s<SUBSEQ_DENSE>(S, tabs, L, ev, ev_rec, err)
                  : entropy_decode_launch_s<SUBSEQ_SPARSE>(S, tabs, L, ev, ev_rec, err);
 }

@@ -264,7 +264,8 @@ namespace kpeg
         readByte( b );  // component count (the reference's loop always reads three triples)
         // extension: a one-component frame is read as what it is (and decoded as grayscale)
         components_ = ( allowGray_ && b == 1 ) ? 1 : 3;
-        bool nonSampled = true;
+        bool nonSampled = true, is420 = components_ == 3;
+        sub420_ = false;
         for ( int i = 0; i < components_; ++i )
         {
             readByte( id );
@@ -272,6 +273,14 @@ namespace kpeg
             readByte( tq );
             if ( ( samp >> 4 ) != 1 || ( samp & 0x0F ) != 1 )
                 nonSampled = false;
+            // extension: luma 2x2 with quantiser 0, both chroma components 1x1 with quantiser 1 (the reference's hard-wired tables)
+            if ( samp != ( i == 0 ? 0x22 : 0x11 ) || tq != ( i == 0 ? 0 : 1 ) )
+                is420 = false;
+        }
+        if ( !nonSampled && allow420_ && is420 )
+        {
+            sub420_ = true;
+            nonSampled = true;
         }
         if ( !nonSampled )
         {
@@ -378,7 +387,7 @@ namespace kpeg
         std::memset( f, 0, sizeof( *f ) );
         f->width = image_.getWidth();
         f->height = image_.getHeight();
-        f->components = gray ? 1 : 0;
+        f->components = gray ? 1 : ( sub420_ ? KPEG_FRAME_420 : 0 );
         for ( int t = 0; t < 2; ++t )
             for ( int k = 0; k < 64; ++k )
                 f->qt[t][k] = QTables_[gray ? 0 : t][k];  // first 64 entries: what MCU.cpp:110-112 reads
@@ -406,7 +415,7 @@ namespace kpeg
     {
         kpeg_frame f;
         const unsigned w = image_.getWidth(), h = image_.getHeight();
-        return !scan_.empty() && sosCount_ == 1 && frameInfo( &f ) && w != 0 && h != 0 && ( allowAnySize_ || ( !( w & 7 ) && !( h & 7 ) ) );
+        return !scan_.empty() && sosCount_ == 1 && frameInfo( &f ) && w != 0 && h != 0 && ( allowAnySize_ || sub420_ || ( !( w & 7 ) && !( h & 7 ) ) );
     }
 
     JPEGDecoder::ResultCode JPEGDecoder::decodeScanData()
@@ -418,7 +427,7 @@ namespace kpeg
         }
         kpeg_frame f;
         const unsigned w = image_.getWidth(), h = image_.getHeight();
-        if ( sosCount_ != 1 || !frameInfo( &f ) || w == 0 || h == 0 || ( !allowAnySize_ && ( ( w & 7 ) || ( h & 7 ) ) ) )
+        if ( sosCount_ != 1 || !frameInfo( &f ) || w == 0 || h == 0 || ( !allowAnySize_ && !sub420_ && ( ( w & 7 ) || ( h & 7 ) ) ) )
         {
             LOG(Logger::Level::ERROR) << "[ FATAL ] Stream is outside what libKPEG decodes without undefined behaviour "
                                          "(two quantisation tables id 0,1; four Huffman tables id 0/1; one scan; "
@@ -434,7 +443,7 @@ namespace kpeg
         }
         int rc;
         const std::vector<kpeg_hip_ctx*>& many = f.restart_interval ? hip::contexts( &why ) : std::vector<kpeg_hip_ctx*>();
-        if ( many.size() > 1 && !( w & 7 ) && !( h & 7 ) && ( w / 8 ) % f.restart_interval == 0 )   // every MCU row starts a restart interval
+        if ( many.size() > 1 && !sub420_ && !( w & 7 ) && !( h & 7 ) && ( w / 8 ) % f.restart_interval == 0 )   // every MCU row starts a restart interval
         {
             // extension (the reference rejects DRI): a restart-interval image goes over $KPEG_HIP_DEVICES GPUs as row stripes,
             // every GPU downloads its own rows

@@ -32,6 +32,7 @@ extern "C" int kpeg_host_parse( const uint8_t* file, size_t size, unsigned flags
         dec.setRestartMarkerSupport( ( flags & KPEG_PARSE_ALLOW_DRI ) != 0 );
         dec.setGrayscaleSupport( ( flags & KPEG_PARSE_ALLOW_GRAY ) != 0 );
         dec.setAnySizeSupport( ( flags & KPEG_PARSE_ALLOW_ANY_SIZE ) != 0 );
+        dec.set420Support( ( flags & KPEG_PARSE_ALLOW_420 ) != 0 );
         dec.openMemory( file, size, "memory.jpg" );
         const int rc = (int)dec.decodeImageFile();
         if ( rc != (int)kpeg::JPEGDecoder::DECODE_DONE )
@@ -39,7 +40,7 @@ extern "C" int kpeg_host_parse( const uint8_t* file, size_t size, unsigned flags
         if ( !dec.frameInfo( frame ) )
             return -1;
         // what decodeScanData() answers for such a file without the extension (the parse alone does not look at the size)
-        if ( !( flags & KPEG_PARSE_ALLOW_ANY_SIZE ) && ( ( frame->width & 7 ) || ( frame->height & 7 ) ) )
+        if ( !( flags & KPEG_PARSE_ALLOW_ANY_SIZE ) && frame->components != KPEG_FRAME_420 && ( ( frame->width & 7 ) || ( frame->height & 7 ) ) )
             return (int)kpeg::JPEGDecoder::ERROR;
         const std::vector<kpeg::UInt8>& s = dec.scanData();
         *scan_len = s.size();
@@ -63,6 +64,7 @@ extern "C" int kpeg_host_decode_file( const char* path, unsigned flags )
         dec.setRestartMarkerSupport( ( flags & KPEG_PARSE_ALLOW_DRI ) != 0 );
         dec.setGrayscaleSupport( ( flags & KPEG_PARSE_ALLOW_GRAY ) != 0 );
         dec.setAnySizeSupport( ( flags & KPEG_PARSE_ALLOW_ANY_SIZE ) != 0 );
+        dec.set420Support( ( flags & KPEG_PARSE_ALLOW_420 ) != 0 );
         if ( !dec.open( path ) )
             return (int)kpeg::JPEGDecoder::ERROR;
         const int rc = (int)dec.decodeImageFile();

@@ -4,7 +4,7 @@
 // must end in ".jpg" (isValidFilename), the PPM lands next to the input, kpeg.log is created
 // in the working directory.  The encode direction (`kpeg in.ppm out.jpg`) belongs to the
 // reference's unfinished encoder and is out of scope here; it reports that and exits.
-// Extensions: `--allow-dri` accepts streams with restart markers, `--allow-gray` one-component files, `--allow-any-size` widths and heights that are not multiples of 8; `--batch` takes any number of files and
+// Extensions: `--allow-dri` accepts streams with restart markers, `--allow-gray` one-component files, `--allow-any-size` widths and heights that are not multiples of 8, `--allow-420` 4:2:0 files; `--batch` takes any number of files and
 // directories and decodes files of identical geometry and tables together (kpeg::decodeFiles).
 #include <cstdlib>
 #include <cstring>
@@ -30,10 +30,11 @@ static void printHelp()
     std::cout << "--batch [--allow-dri] <files and directories...> : Decompress many JPEG images (extension)" << std::endl;
     std::cout << "--allow-gray <filename.jpg>     : ... accepting one-component (grayscale) files (extension)" << std::endl;
     std::cout << "--allow-any-size <filename.jpg> : ... accepting widths and heights that are not multiples of 8 (extension)" << std::endl;
+    std::cout << "--allow-420 <filename.jpg>      : ... accepting 4:2:0 files of any size (extension)" << std::endl;
     std::cout << "-h                              : Print this help message and exit" << std::endl;
 }
 
-static int decodeJPEG( const std::string& filename, bool allowDRI, bool allowGray = false, bool allowAnySize = false )
+static int decodeJPEG( const std::string& filename, bool allowDRI, bool allowGray = false, bool allowAnySize = false, bool allow420 = false )
 {
     if ( !kpeg::isValidFilename( filename ) )
     {
@@ -44,6 +45,7 @@ static int decodeJPEG( const std::string& filename, bool allowDRI, bool allowGra
     decoder.setRestartMarkerSupport( allowDRI );
     decoder.setGrayscaleSupport( allowGray );
     decoder.setAnySizeSupport( allowAnySize );
+    decoder.set420Support( allow420 );
     decoder.open( filename );
     if ( decoder.decodeImageFile() == kpeg::JPEGDecoder::ResultCode::DECODE_DONE )
         decoder.dumpRawData();
@@ -104,6 +106,8 @@ int main( int argc, char** argv )
             return decodeJPEG( argv[2], false, true );
         if ( argc == 3 && std::string( argv[1] ) == "--allow-any-size" )
             return decodeJPEG( argv[2], false, false, true );
+        if ( argc == 3 && std::string( argv[1] ) == "--allow-420" )
+            return decodeJPEG( argv[2], false, false, false, true );
         if ( argc == 3 )
         {
             LOG(kpeg::Logger::Level::ERROR) << "The PPM->JPEG encoder of libKPEG is unfinished upstream and is not part of this build." << std::endl;

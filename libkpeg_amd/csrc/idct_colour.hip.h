@@ -195,6 +195,47 @@ __global__ __launch_bounds__(64) void k_idct_colour_exact(IdctParams p, QTables 
     o[2] = (uint8_t)(px >> 16);
 }
 
+// ---- 4:2:0 (extension): reference-order evaluation of every sample of a 16x16 MCU --------
+// One 256-thread block per MCU.  coef: [mcu][Y00 Y01 Y10 Y11 Cb Cr][64] natural order; every thread evaluates one luma
+// sample, the first 128 also one chroma sample each, in the reference's own order (as k_idct_colour_exact); then thread
+// (py, px) converts its pixel with the chroma sample that covers it (each repeated 2x2: no interpolation, no arithmetic
+// the reference does not have).  rgb is the picture padded to whole MCUs (pitch bytes per row); the caller crops.
+__global__ __launch_bounds__(256) void k_idct_colour_exact_420(const int16_t* __restrict__ coef, uint8_t* __restrict__ rgb, uint32_t mcus_w,
+                                                              uint32_t pitch, QTables qt)
+{
+    __shared__ float s_fc[6][64];
+    __shared__ int s_S[6][64];
+    const uint32_t mcu = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 384; i += 256) {
+        const int blk = i >> 6, k = i & 63;
+        const int F = (int)coef[(size_t)mcu * 384 + i] * (int)qt.q[blk < 4 ? 0 : 1][k];
+        s_fc[blk][k] = cc_of(k >> 3, k & 7) * (float)F;
+    }
+    __syncthreads();
+    for (int i = tid; i < 384; i += 256) {
+        const int blk = i >> 6, x = (i >> 3) & 7, y = i & 7;
+        float sum = 0.0f;
+        for (int k = 0; k < 64; ++k) {
+            const float fc = s_fc[blk][k];
+            if (fc != 0.0f) {
+                const double t = ((double)fc * c_cos[x * 8 + (k >> 3)]) * c_cos[y * 8 + (k & 7)];
+                sum = (float)((double)sum + t);
+            }
+        }
+        s_S[blk][x * 8 + y] = level_shift((float)(0.25 * (double)sum));
+    }
+    __syncthreads();
+    const int py = tid >> 4, px = tid & 15;
+    const uint32_t p = colour_exact(s_S[(py >> 3) * 2 + (px >> 3)][(py & 7) * 8 + (px & 7)], s_S[4][(py >> 1) * 8 + (px >> 1)],
+                                    s_S[5][(py >> 1) * 8 + (px >> 1)]);
+    const uint32_t tr = mcu / mcus_w, tc = mcu % mcus_w;
+    uint8_t* o = rgb + (size_t)(tr * 16 + py) * pitch + (size_t)(tc * 16 + px) * 3;
+    o[0] = (uint8_t)p;
+    o[1] = (uint8_t)(p >> 8);
+    o[2] = (uint8_t)(p >> 16);
+}
+
 // ---- mode 0: fast path + exact re-evaluation ---------------------------------------------
 
 // Error bound (derivation and numeric check: tools/idct_bound.py, DESIGN.md "K4 exactness"):

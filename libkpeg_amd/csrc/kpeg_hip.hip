@@ -367,8 +367,8 @@ static int check_frame(kpeg_hip_ctx* ctx, const kpeg_frame* f, bool any_size = f
         ctx->last_error = any_size ? "width/height must be 1..65535" : "width/height must be non-zero multiples of 8 (SURVEY.md A.1)";
         return KPEG_HIP_E_ARG;
     }
-    if (f->components != 0 && f->components != 1 && f->components != 3) {
-        ctx->last_error = "components must be 0 / 3 (Y Cb Cr 4:4:4) or 1 (grayscale)";
+    if (f->components != 0 && f->components != 1 && f->components != 3 && !(any_size && f->components == KPEG_FRAME_420)) {
+        ctx->last_error = "components must be 0 / 3 (Y Cb Cr 4:4:4), 1 (grayscale) or, at the whole-image entry points, KPEG_FRAME_420";
         return KPEG_HIP_E_UNSUPPORTED;
     }
     return KPEG_HIP_OK;
@@ -504,7 +504,7 @@ extern "C" int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
 // tiles (width a multiple of 64), and never for the reference-order cross-check kernel, which reads dense blocks.
 static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t scan_bytes, uint64_t nmcu)
 {
-    if (ctx->coef_layout == 1 || ctx->idct_mode == 1 || f->components == 1) return false;
+    if (ctx->coef_layout == 1 || ctx->idct_mode == 1 || f->components == 1 || f->components == KPEG_FRAME_420) return false;
     if ((f->width / 8) % TILE_MCUS != 0) return false;
     const bool dense = ctx->subseq ? ctx->subseq >= SUBSEQ_DENSE : scan_bytes * 8 >= nmcu * 64 * 4;   // entropy_decode_launch's rule
     if (ctx->coef_layout == 2) return true;
@@ -524,7 +524,8 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
         ctx->last_error = "Huffman table is not a usable prefix code";
         return KPEG_HIP_E_TABLES;
     }
-    if ((rc = grow(ctx, &ctx->d_ebound, &ctx->ebound_cap, (size_t)nmcu * 3 * sizeof(float)))) return rc;
+    const bool sub420 = f->components == KPEG_FRAME_420;   // nmcu then counts 16x16 MCUs of six blocks
+    if ((rc = grow(ctx, &ctx->d_ebound, &ctx->ebound_cap, (size_t)nmcu * (sub420 ? 6 : 3) * sizeof(float)))) return rc;
     EntropyLaunch L;
     L.stream = ctx->stream;
     L.d_scan = d_scan;
@@ -539,6 +540,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.warm = ctx->warm;
     L.subseq = ctx->subseq;
     L.gray = f->components == 1 ? 1u : 0u;
+    L.sub420 = sub420 ? 1u : 0u;
     if (compact) {
         // a record takes at least two bits of the stream (a one-bit code and a one-bit magnitude), a block holds at most 63
         const uint64_t bytes = batch ? batch->total_len : (uint64_t)scan_len;
@@ -662,10 +664,45 @@ static int decode_any_size(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t
     return KPEG_HIP_OK;
 }
 
+// 4:2:0 extension: K0-K2 with six blocks per MCU, the reference-order kernel on 16x16 MCUs into the padded picture, crop.
+// (No fast path yet: every sample is evaluated in the reference's order -- exact by construction, about 8 Mpixel/ms.)
+static int decode_420(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint8_t* d_rgb)
+{
+    int rc = check_frame(ctx, f, true);
+    if (rc) return rc;
+    if (!d_scan || !scan_len || !d_rgb) return KPEG_HIP_E_ARG;
+    if (reinterpret_cast<uintptr_t>(d_rgb) & 7) {
+        ctx->last_error = "rgb buffer must be 8-byte aligned";
+        return KPEG_HIP_E_ARG;
+    }
+    const uint32_t mw = (f->width + 15) / 16, mh = (f->height + 15) / 16;
+    const size_t nmcu = (size_t)mw * mh;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, nmcu * 384 * sizeof(int16_t)))) return rc;
+    if ((rc = grow(ctx, &ctx->d_pad, &ctx->pad_cap, nmcu * 768))) return rc;
+    begin_call(ctx);
+    if (!ctx->status_clean && !ctx->keep_status) HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, STATUS_BYTES, ctx->stream));
+    ctx->status_clean = false;
+    mark(ctx, kpeg_hip_ctx::EV_BEGIN);
+    rc = run_entropy(ctx, f, d_scan, scan_len, (uint32_t)nmcu, (int16_t*)ctx->d_coef);
+    if (rc) return rc;
+    QTables qt;
+    natural_qtables(f, &qt);
+    hipLaunchKernelGGL(k_idct_colour_exact_420, dim3((unsigned)nmcu), dim3(256), 0, ctx->stream, (const int16_t*)ctx->d_coef, (uint8_t*)ctx->d_pad,
+                       mw, mw * 48, qt);
+    const uint64_t total = (uint64_t)f->width * f->height * 3;
+    hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_pad, mw * 48, d_rgb,
+                       f->width * 3, total);
+    HIPCHK(ctx, hipGetLastError());
+    mark(ctx, kpeg_hip_ctx::EV_IDCT);
+    return finish_async(ctx, false);
+}
+
 extern "C" int kpeg_hip_decode_scan_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len,
                                         uint8_t* d_rgb)
 {
     if (!f) return KPEG_HIP_E_ARG;
+    if (f->components == KPEG_FRAME_420) return decode_420(ctx, f, d_scan, scan_len, d_rgb);
     if ((f->width & 7) || (f->height & 7)) return decode_any_size(ctx, f, d_scan, scan_len, d_rgb);
     return kpeg_hip_decode_stripe_dev(ctx, f, d_scan, scan_len, 0, f->height / 8, d_rgb);
 }

@@ -822,3 +822,169 @@ int kpeg_oracle_decode_gray(const uint8_t* file, size_t n, uint8_t** rgb, uint32
     *height = j.height;
     return KPEG_ORACLE_DECODE_DONE;
 }
+
+/* ------------------------------------------------------------------ */
+/* Extension: 4:2:0 (luma sampled 2x2, both chroma components 1x1)      */
+/* ------------------------------------------------------------------ */
+/* The reference answers TERMINATE on any sampling factor other than 1x1 (parseSOF0Segment, Decoder.cpp:339-356; fixture
+ * rej_420.jpg).  PARITY UNPINNED: what is restated here is the reference's own per-block path -- decodeScanData's symbol
+ * loop with quirk Q1, dequantisation, computeIDCT, performLevelShift -- applied to the six blocks of a 16x16 MCU in T.81's
+ * order (Y00 Y01 Y10 Y11 Cb Cr: table pair 0 for the four Y blocks, 1 for Cb and Cr, one DC predictor per component),
+ * every chroma sample repeated over its 2x2 luma samples (no interpolation: the simplest upsampling T.81 allows and the
+ * only one that adds no arithmetic of its own), then convertYCbCrToRGB (MCU.cpp:247-279) per pixel, the picture padded to
+ * whole MCUs and cropped as Image::createImageFromMCUs crops.  Checked against Pillow's decoder (libjpeg, which
+ * interpolates chroma) within what that difference allows (tests/test_420.py), not against the reference. */
+int kpeg_oracle_decode_420(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads)
+{
+    kpeg_oracle_jfif j;
+    memset(&j, 0, sizeof(j));
+    size_t pos = 2;
+    if (n < 4 || file[0] != 0xFF || file[1] != 0xD8) return KPEG_ORACLE_ERROR;
+    int have_sof = 0;
+    uint32_t ri = 0;
+    while (pos + 4 <= n) {
+        if (file[pos] != 0xFF) return KPEG_ORACLE_ERROR;
+        const uint8_t m = file[pos + 1];
+        const size_t len = ((size_t)file[pos + 2] << 8) | file[pos + 3];
+        if (len < 2 || pos + 2 + len > n) return KPEG_ORACLE_ERROR;
+        const uint8_t* p = file + pos + 4;
+        const size_t body = len - 2;
+        if (m == 0xDB) {
+            for (size_t o = 0; o + 65 <= body; o += 65) {
+                if (p[o] >> 4) return KPEG_ORACLE_OUT_OF_CONTRACT;   /* 16-bit tables */
+                const int id = p[o] & 0x0F;
+                if (id > 1) return KPEG_ORACLE_OUT_OF_CONTRACT;
+                for (int i = 0; i < 64; ++i) j.qt[id][i] = p[o + 1 + i];
+                j.nqt |= 1 << id;
+            }
+        } else if (m == 0xC0) {
+            if (body < 15 || p[0] != 8 || p[5] != 3 || p[7] != 0x22 || p[8] != 0 || p[10] != 0x11 || p[11] != 1 || p[13] != 0x11 || p[14] != 1)
+                return KPEG_ORACLE_OUT_OF_CONTRACT;
+            j.height = ((uint32_t)p[1] << 8) | p[2];
+            j.width = ((uint32_t)p[3] << 8) | p[4];
+            have_sof = 1;
+        } else if (m == 0xC4) {
+            size_t o = 0;
+            while (o + 17 <= body) {
+                const int cls = (p[o] >> 4) & 1, id = p[o] & 0x0F;
+                int total = 0;
+                for (int i = 0; i < 16; ++i) total += p[o + 1 + i];
+                if (id > 1 || o + 17 + (size_t)total > body || total > 256) return KPEG_ORACLE_OUT_OF_CONTRACT;
+                kpeg_oracle_dht* d = &j.dht[cls][id];
+                memset(d, 0, sizeof(*d));
+                memcpy(d->counts, p + o + 1, 16);
+                memcpy(d->symbols, p + o + 17, (size_t)total);
+                d->nsymbols = total;
+                d->defined = 1;
+                o += 17 + (size_t)total;
+            }
+        } else if (m == 0xDD) {
+            if (body >= 2) ri = ((uint32_t)p[0] << 8) | p[1];
+        } else if (m == 0xDA) {
+            /* three components, Y with table pair 0, Cb and Cr with pair 1: the reference's hard-wired selection (Decoder.cpp:704) */
+            if (body < 7 || p[0] != 3 || p[2] != 0x00 || p[4] != 0x11 || p[6] != 0x11) return KPEG_ORACLE_OUT_OF_CONTRACT;
+            pos += 2 + len;
+            break;
+        } else if (m == 0xC1 || m == 0xC2) {
+            return KPEG_ORACLE_TERMINATE;
+        }
+        pos += 2 + len;
+    }
+    if (j.nqt == 3) j.nqt = 2;
+    if (!have_sof || j.nqt != 2 || !have_tables(&j) || j.width == 0 || j.height == 0) return KPEG_ORACLE_OUT_OF_CONTRACT;
+    uint8_t* scan = (uint8_t*)malloc(n - pos + 2);
+    size_t sl = 0;
+    while (pos < n) {   /* scanImageData's rule (Decoder.cpp:544-574) */
+        uint8_t b = file[pos++];
+        if (b == 0xFF) {
+            const uint8_t nx = pos < n ? file[pos++] : 0xFF;
+            if (nx == 0xD9) break;
+            scan[sl++] = 0xFF;
+            b = nx;
+        }
+        scan[sl++] = b;
+    }
+    const uint32_t mw = (j.width + 15) / 16, mh = (j.height + 15) / 16, nmcu = mw * mh;
+    int16_t* coef = (int16_t*)calloc((size_t)nmcu * 384, sizeof(int16_t));   /* [mcu][Y00 Y01 Y10 Y11 Cb Cr][64] */
+    codebook cb[2][2];
+    for (int c = 0; c < 2; ++c)
+        for (int i = 0; i < 2; ++i) build_codebook(&j.dht[c][i], &cb[c][i]);
+    uint8_t* tmp = (uint8_t*)malloc(sl + 4);
+    int rc = 0;
+    size_t at = 0;
+    for (uint32_t done = 0; done < nmcu && !rc;) {
+        size_t e = sl, ulen;
+        uint32_t cnt = nmcu - done;
+        if (ri) {   /* every restart interval as a stream of its own, as kpeg_oracle_entropy_decode_rst does */
+            for (e = at; e < sl; ++e)
+                if (scan[e] == 0xFF && e + 1 < sl && scan[e + 1] >= 0xD0 && scan[e + 1] <= 0xD7) break;
+            memcpy(tmp, scan + at, e - at);
+            tmp[e - at] = tmp[e - at + 1] = 0;
+            ulen = kpeg_oracle_unstuff(tmp, e - at + 2, tmp);
+            if (cnt > ri) cnt = ri;
+        } else {
+            ulen = kpeg_oracle_unstuff(scan, sl, tmp);
+        }
+        bitrd b = {tmp, (uint64_t)ulen * 8, 0};
+        int pred[3] = {0, 0, 0}, zz[64];
+        for (uint32_t m = done; m < done + cnt && !rc; ++m)
+            for (int blk = 0; blk < 6 && !rc; ++blk) {
+                const int comp = blk < 4 ? 0 : blk - 3, id = blk < 4 ? 0 : 1;
+                if (!decode_block(&b, &cb[0][id], &cb[1][id], zz)) {
+                    rc = KPEG_ORACLE_OUT_OF_CONTRACT;
+                    break;
+                }
+                pred[comp] += zz[0];
+                zz[0] = pred[comp];
+                for (int k = 0; k < 64; ++k) {
+                    if (zz[k] < -32768 || zz[k] > 32767) rc = KPEG_ORACLE_OUT_OF_CONTRACT;
+                    coef[((size_t)m * 6 + blk) * 64 + k] = (int16_t)zz[k];
+                }
+            }
+        done += cnt;
+        at = e + 2;
+    }
+    free(tmp);
+    free(scan);
+    if (rc) {
+        free(coef);
+        return rc;
+    }
+    init_tables();
+    (void)kpeg_oracle_zz_to_rowmajor(0);
+    uint8_t* out = (uint8_t*)malloc((size_t)j.width * j.height * 3);
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (long tr = 0; tr < (long)mh; ++tr)
+        for (uint32_t tc = 0; tc < mw; ++tc) {
+            int S[6][64], F[64];
+            float ic[64];
+            const int16_t* c6 = coef + ((size_t)tr * mw + tc) * 384;
+            for (int blk = 0; blk < 6; ++blk) {
+                dequant(c6 + blk * 64, j.qt[blk < 4 ? 0 : 1], F);
+                idct_rowmajor(F, ic);
+                for (int i = 0; i < 64; ++i) S[blk][i] = (int)(roundl((long double)ic[i]) + 128);
+            }
+            for (int py = 0; py < 16; ++py)
+                for (int px = 0; px < 16; ++px) {
+                    const uint32_t y = (uint32_t)tr * 16 + py, x = tc * 16 + px;
+                    if (y >= j.height || x >= j.width) continue;   /* the rows and columns createImageFromMCUs pops */
+                    const float Y = (float)S[(py >> 3) * 2 + (px >> 3)][(py & 7) * 8 + (px & 7)];
+                    const float Cb = (float)S[4][(py >> 1) * 8 + (px >> 1)], Cr = (float)S[5][(py >> 1) * 8 + (px >> 1)];
+                    const int R = (int)floor(Y + 1.402 * (1.0 * Cr - 128.0));
+                    const int G = (int)floor(Y - 0.344136 * (1.0 * Cb - 128.0) - 0.714136 * (1.0 * Cr - 128.0));
+                    const int B = (int)floor(Y + 1.772 * (1.0 * Cb - 128.0));
+                    uint8_t* o = out + ((size_t)y * j.width + x) * 3;
+                    o[0] = (uint8_t)clamp255(R);
+                    o[1] = (uint8_t)clamp255(G);
+                    o[2] = (uint8_t)clamp255(B);
+                }
+        }
+    free(coef);
+    *rgb = out;
+    *width = j.width;
+    *height = j.height;
+    return KPEG_ORACLE_DECODE_DONE;
+}

@@ -101,6 +101,10 @@ int kpeg_oracle_decode_gray(const uint8_t* file, size_t n, uint8_t** rgb, uint32
  * all MCUs of the padded picture decoded, cropped as Image::createImageFromMCUs crops.  See kpeg_oracle.c. */
 int kpeg_oracle_decode_any_size(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads);
 
+/* Extension (parity unpinned: the reference answers TERMINATE on sampling factors other than 1x1): 4:2:0 files, any size,
+ * chroma samples repeated 2x2.  See kpeg_oracle.c. */
+int kpeg_oracle_decode_420(const uint8_t* file, size_t n, uint8_t** rgb, uint32_t* width, uint32_t* height, int nthreads);
+
 /* Header of Image::dumpRawData (Image.cpp:124-127). Returns its length. */
 size_t kpeg_oracle_ppm_header(uint32_t width, uint32_t height, char* buf, size_t cap);
 

@@ -198,6 +198,21 @@ def oracle_decode_any_size(data, nthreads=8):
     return st, a
 
 
+def oracle_decode_420(data, nthreads=8):
+    """The 4:2:0 extension (oracle/kpeg_oracle.c: parity unpinned).  Returns (status, rgb or None)."""
+    L = oracle()
+    L.kpeg_oracle_decode_420.restype = ctypes.c_int
+    L.kpeg_oracle_decode_420.argtypes = L.kpeg_oracle_decode.argtypes
+    rgb = ctypes.POINTER(ctypes.c_uint8)()
+    w, h = ctypes.c_uint32(), ctypes.c_uint32()
+    st = L.kpeg_oracle_decode_420(data, len(data), ctypes.byref(rgb), ctypes.byref(w), ctypes.byref(h), nthreads)
+    if st != DECODE_DONE:
+        return st, None
+    a = np.ctypeslib.as_array(rgb, shape=(h.value, w.value, 3)).copy()
+    L.free(rgb)
+    return st, a
+
+
 def oracle_decode_gray(data, nthreads=8):
     """The one-component extension (oracle/kpeg_oracle.c: parity unpinned, the reference cannot decode these).
     Returns (status, rgb or None)."""

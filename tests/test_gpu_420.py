@@ -1,0 +1,130 @@
+"""The 4:2:0 extension on the GPU: kpeg_frame.components = KPEG_FRAME_420 through the whole-image entry points against
+the oracle's restatement (parity unpinned, see tests/test_420.py), bit for bit."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import kpeg_testlib as T
+from test_420 import _photo, encode420
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import libkpeg_amd
+    c = libkpeg_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _check(ctx, data, dri=False):
+    import libkpeg_amd as K
+    st, want = T.oracle_decode_420(data)
+    assert st == T.DECODE_DONE
+    rc, frame, scan = K.host_parse(data, allow_dri=dri, allow_420=True)
+    assert rc == K.DECODE_DONE and frame.components == K.FRAME_420
+    got = ctx.decode_scan(frame, scan)
+    assert got.shape == want.shape
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, "first mismatches (y,x,c) %s of %d" % (bad[:8].tolist(), len(bad))
+    return frame, scan, want
+
+
+@pytest.mark.parametrize("w,h,q,kw", [(16, 16, 75, {}), (1, 1, 80, {}), (17, 9, 90, {}), (640, 424, 90, {}), (333, 201, 50, {"optimize": True}),
+                                      (640, 424, 97, {}), (320, 200, 85, {"restart_marker_blocks": 3}), (640, 400, 75, {"restart_marker_rows": 1})])
+def test_photograph_crops_match_the_oracle(ctx, w, h, q, kw):
+    """One MCU to 0.27 Mpixel, sparse (96-bit sub-sequences) and dense (q97: the 384-bit path) streams, optimised tables,
+    restart intervals (in 16x16 MCUs), sizes that are not multiples of 16."""
+    pytest.importorskip("PIL.Image")
+    data = encode420(_photo()[:h, :w], quality=q, **kw)
+    _check(ctx, data, bool(kw.get("restart_marker_blocks") or kw.get("restart_marker_rows")))
+
+
+@pytest.mark.parametrize("w,h", [(1920, 1080), (4000, 3000)])
+def test_large_synthetic_pictures_match_the_oracle(ctx, w, h):
+    """Millions of pixels: many K1/K2 workgroups, blocks and MCUs split across sub-sequences and workgroups, flat parts
+    (quirk Q1 blocks), saturated colour edges."""
+    pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(w + h)
+    y, x = np.mgrid[0:h, 0:w]
+    px = np.stack([x * 255.0 / (w - 1), y * 255.0 / (h - 1), ((x // 64 + y // 64) % 2) * 255.0], -1)
+    px[: h // 2, : w // 2] += rng.normal(0, 12, (h // 2, w // 2, 3))
+    px[h // 2:, w // 2:] = (200, 30, 90)       # a flat quarter: DC differences of zero
+    _check(ctx, encode420(np.clip(px, 0, 255).astype(np.uint8), quality=80))
+
+
+def test_the_real_references_reject_fixture_decodes(ctx):
+    _check(ctx, open(os.path.join(T.GOLDEN, "rej_420.jpg"), "rb").read())
+
+
+def test_420_then_444_then_gray_on_one_context(ctx):
+    import libkpeg_amd as K
+    pytest.importorskip("PIL.Image")
+    d420 = encode420(_photo()[:100, :150], quality=85)
+    d444 = T.synth_jpeg(152, 104, seed=3, sigma=20.0)
+    st, w444 = T.oracle_decode(d444)
+    p = T.oracle_parse(d444)
+    g = open(os.path.join(T.GOLDEN, "gray_ramp_64x48_q75.jpg"), "rb").read()
+    st, wg = T.oracle_decode_gray(g)
+    rcg, fg, sg = K.host_parse(g, allow_gray=True)
+    for _ in range(2):
+        _check(ctx, d420)
+        assert np.array_equal(ctx.decode_scan(T.make_frame(p), p.scan), w444)
+        assert np.array_equal(ctx.decode_scan(fg, sg), wg)
+
+
+def test_corrupt_420_streams_report_and_recover(ctx):
+    import libkpeg_amd as K
+    pytest.importorskip("PIL.Image")
+    data = encode420(_photo()[:208, :320], quality=85)
+    frame, scan, want = _check(ctx, data)
+    rng = np.random.default_rng(9)
+    failed = 0
+    for case in range(40):
+        s = scan.copy()
+        if case % 2:
+            s = s[:int(rng.integers(1, s.size))].copy()
+        else:
+            for _ in range(4):
+                s[int(rng.integers(0, s.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        try:
+            ctx.decode_scan(frame, s)
+        except K.KpegError as e:
+            assert e.code == K.E_STREAM, e
+            failed += 1
+    assert failed > 5
+    assert np.array_equal(ctx.decode_scan(frame, scan), want)
+
+
+def test_other_entry_points_reject_420(ctx):
+    import torch
+    import libkpeg_amd as K
+    pytest.importorskip("PIL.Image")
+    data = encode420(_photo()[:64, :64], quality=85)
+    rc, frame, scan = K.host_parse(data, allow_420=True)
+    d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
+    d_rgb = torch.zeros((64, 64, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(K.KpegError) as e:
+        ctx.decode_stripe_dev(frame, d_scan.data_ptr(), d_scan.numel(), 0, 8, d_rgb.data_ptr())
+    assert e.value.code == K.E_UNSUPPORTED
+    with pytest.raises(K.KpegError) as e:
+        ctx.decode_batch_dev(frame, [d_scan.data_ptr()], [d_scan.numel()], [d_rgb.data_ptr()])
+    assert e.value.code == K.E_UNSUPPORTED
+
+
+def test_cli_allow_420(tmp_path):
+    import subprocess
+    import libkpeg_amd as K
+    pytest.importorskip("PIL.Image")
+    data = encode420(_photo()[:201, :333], quality=85)
+    dst = tmp_path / "p420.jpg"
+    dst.write_bytes(data)
+    subprocess.run([K.CLI, str(dst)], cwd=tmp_path, capture_output=True, timeout=120)
+    assert not os.path.exists(tmp_path / "p420.ppm")          # the reference's answer: TERMINATE, nothing written
+    out = subprocess.run([K.CLI, "--allow-420", str(dst)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-500:]
+    st, want = T.oracle_decode_420(data)
+    assert open(tmp_path / "p420.ppm", "rb").read() == T.ppm_header(333, 201) + want.tobytes()
