@@ -36,7 +36,7 @@ def _check(ctx, data, dri=False):
 @pytest.mark.parametrize("w,h,q,kw", [(16, 16, 75, {}), (1, 1, 80, {}), (17, 9, 90, {}), (640, 424, 90, {}), (333, 201, 50, {"optimize": True}),
                                       (640, 424, 97, {}), (320, 200, 85, {"restart_marker_blocks": 3}), (640, 400, 75, {"restart_marker_rows": 1})])
 def test_photograph_crops_match_the_oracle(ctx, w, h, q, kw):
-    """One MCU to 0.27 Mpixel, sparse (96-bit sub-sequences) and dense (q97: the 384-bit path) streams, optimised tables,
+    """One MCU to 0.27 Mpixel, sparse and dense streams, optimised tables,
     restart intervals (in 16x16 MCUs), sizes that are not multiples of 16."""
     pytest.importorskip("PIL.Image")
     data = encode420(_photo()[:h, :w], quality=q, **kw)
@@ -54,6 +54,18 @@ def test_large_synthetic_pictures_match_the_oracle(ctx, w, h):
     px[: h // 2, : w // 2] += rng.normal(0, 12, (h // 2, w // 2, 3))
     px[h // 2:, w // 2:] = (200, 30, 90)       # a flat quarter: DC differences of zero
     _check(ctx, encode420(np.clip(px, 0, 255).astype(np.uint8), quality=80))
+
+
+def test_both_sub_sequence_sizes(ctx):
+    """4:2:0 streams take the 384-bit sub-sequences by default; the 96-bit kernels are the same code and must agree."""
+    pytest.importorskip("PIL.Image")
+    data = encode420(_photo()[:424, :640], quality=88)
+    try:
+        for ss in (96, 384):
+            assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, ss) == 0
+            _check(ctx, data)
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 0)
 
 
 def test_the_real_references_reject_fixture_decodes(ctx):
