@@ -27,3 +27,13 @@ for ss in (96, 384):
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3; ctx.sync()
     ctx.set_profiling(True); ctx.decode_scan_dev(f, d_scan.data_ptr(), d_scan.numel(), d_rgb.data_ptr()); ctx.sync(); ctx.set_profiling(False)
     print("sub-sequences of %d bits: %.3f ms, K1 %.3f ms, launches with work %s" % (ss, ms, ctx.timings()["huff_sync_ms"], ctx.timings().get("sync_rounds")))
+if hasattr(ctx.lib, "kpeg_hip_debug_entropy_stamps"):
+    import ctypes
+    ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 0)
+    ctx.decode_scan_dev(f, d_scan.data_ptr(), d_scan.numel(), d_rgb.data_ptr()); ctx.sync()
+    a = np.zeros(8192 * 16, np.uint64)
+    ctx.lib.kpeg_hip_debug_entropy_stamps(0, a.ctypes.data_as(ctypes.c_void_p), a.size)
+    a = a.reshape(8192, 16); a = a[a[:, 0] != 0]
+    rounds = (a[:, 5] >> np.uint64(32)).astype(int); runs = (a[:, 5] & np.uint64(0xFFFFFFFF)).astype(int)
+    print("K1 pass 0 (stats build): %d wavefronts, rounds per wave: median %d p90 %d max %d; decodes per wave median %d" % (
+        len(a), np.median(rounds), np.percentile(rounds, 90), rounds.max(), np.median(runs)))
