@@ -293,6 +293,7 @@ struct EntropyLaunch {
     uint32_t fault = 0;                  // fault injection (test hook): bit 0 K0's, bit 1 K1's workgroup 0 never publishes
     uint32_t gray = 0;                   // one-component stream (kpeg_frame::components == 1)
     uint32_t sub420 = 0;                 // 4:2:0 (extension, dense layout): nmcu counts 16x16 MCUs of six blocks
+    uint32_t force_k0 = 0;               // test / experiment hook: run K0 even where K1 and K2 could un-stuff for themselves
     // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
     // from the known state, DC predictors reset): d_scan / scan_len are unused, restart_interval = MCUs per image
     uint32_t nimg = 0;
@@ -727,6 +728,152 @@ __device__ __forceinline__ void stage_bits(uint32_t* lds, uint32_t cap, const ui
     for (uint32_t j = threadIdx.x; j < cap; j += blockDim.x) lds[j] = j < nw ? g[w0 + j] : 0u;
 }
 
+// ------------------------------------------------------------------------------------------
+// Streams without restart markers, one image: no K0.  The sub-sequences are then chunks of S / 8 bytes of the scan AS IT IS
+// (still byte-stuffed), and every workgroup of K1 and K2 un-stuffs the chunks it stages while it stages them: a chunk
+// becomes 8 * (its kept bytes) bits of the workgroup's slice in LDS, start[] says where.  Bit positions that leave a
+// workgroup (exit states) are VIRTUAL: chunk << VSHIFT | bit inside the chunk's kept bits (a decode ends less than a symbol,
+// < 32 bits, past its chunk, and a chunk keeps at least half its bytes: the position lies inside the next chunk); the same
+// stream position has the same virtual position in every workgroup.  byteStuffScanData's rule (Decoder.cpp:631-650): a
+// 00 after an FF goes, except as the very last byte of the scan.
+template <int S>
+struct StuffedGeom {
+    static constexpr uint32_t BYTES = S / 8;
+    static constexpr uint32_t VSHIFT = S <= 96 ? 7 : 9;
+    static constexpr uint32_t EXTRA = STAGE_MARGIN * 4 / BYTES;   // chunks staged past the workgroup's last one: the decoders' look-ahead
+};
+
+// Stages chunks [c0, c0 + nst) (nst <= SYNC_WG + EXTRA) of scan[0, n): lds receives the kept bytes as big-endian words from
+// bit 0 (what the K0 path stages), start[j] the first bit of chunk c0 + j (start[nst] = the end).  red: SYNC_WG / 64 + 1
+// words of scratch.  One round: thread t takes chunk t and, if t < nst - SYNC_WG, also chunk SYNC_WG + t (the few staged
+// for the decoders' look-ahead); all loads are issued before anything waits for one.
+template <int S>
+struct StuffedChunk {
+    static constexpr uint32_t BYTES = S / 8, WORDS = BYTES / 4;
+    uint32_t w[WORDS];    // the chunk's bytes, little-endian words
+    uint32_t drop[WORDS]; // bit 7 of every byte that goes: a 00 after an FF that is not the scan's last byte
+    uint32_t nb, nk;      // bytes that exist, bytes kept
+
+    // (only words that hold at least one byte of the scan are touched: an aligned word never straddles the end of a mapping,
+    // so nothing outside the caller's buffer is read that does not share a word with it)
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ scan, uint32_t n, uint64_t b0, bool have, uint32_t& prev)
+    {
+        nb = have ? (uint32_t)min((uint64_t)BYTES, (uint64_t)n - b0) : 0u;
+        prev = 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < WORDS; ++q) w[q] = 0u;
+        if (have) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(scan) + b0;
+            const uint32_t* ap = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(a & 3);
+            const uintptr_t lo = reinterpret_cast<uintptr_t>(scan) & ~(uintptr_t)3, hi = (reinterpret_cast<uintptr_t>(scan) + n + 3) & ~(uintptr_t)3;
+            uint32_t raw[WORDS + 1];
+#pragma unroll
+            for (uint32_t q = 0; q < WORDS + 1; ++q) {
+                const uintptr_t wa = reinterpret_cast<uintptr_t>(ap + q);
+                raw[q] = (wa >= lo && wa < hi) ? ap[q] : 0u;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < WORDS; ++q) w[q] = __builtin_amdgcn_alignbyte(raw[q + 1], raw[q], sh);
+            if (b0 > 0) prev = scan[b0 - 1];
+        }
+    }
+    __device__ __forceinline__ void flags(uint32_t n, uint64_t b0, uint32_t prev)
+    {
+        uint32_t dropped = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < WORDS; ++q) {
+            const uint32_t before = (w[q] << 8) | (q ? w[q - 1] >> 24 : prev);      // every byte's predecessor
+            const uint32_t z = ~(((w[q] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[q]) & 0x80808080u;            // bytes that are 00
+            const uint32_t nf = ~before;
+            const uint32_t f = ~(((nf & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | nf) & 0x80808080u;               // predecessors that are FF
+            uint32_t d = z & f;
+            // bytes that do not exist, and the scan's last byte, stay out of it
+            const uint32_t first = q * 4;
+            const uint32_t lim = b0 + nb >= n ? (nb ? nb - 1 : 0u) : nb;   // bytes [0, lim) may go
+            const uint32_t keepbytes = lim > first ? min(lim - first, 4u) : 0u;
+            d &= keepbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * keepbytes)) - 1u);
+            drop[q] = d;
+            dropped += __popc(d);
+        }
+        nk = nb - dropped;
+    }
+    // the kept bytes to lds bytes [pos, pos + nk), big-endian words
+    __device__ __forceinline__ void scatter(uint8_t* lb, uint32_t pos) const
+    {
+#pragma unroll
+        for (uint32_t k = 0; k < BYTES; ++k) {
+            const bool keep = k < nb && !((drop[k >> 2] >> ((k & 3) * 8 + 7)) & 1u);
+            if (keep) {
+                lb[pos ^ 3u] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+                pos++;
+            }
+        }
+    }
+};
+
+// In two steps, so that the caller can put its other global loads (the tables) between the chunks' loads and their use.
+template <int S>
+struct StuffedStage {
+    StuffedChunk<S> A, B;
+    uint32_t prevA, prevB, n1, n2, c0;
+
+    __device__ __forceinline__ void begin(const uint8_t* __restrict__ scan, uint32_t n, uint32_t c0_, uint32_t nst)
+    {
+        constexpr uint32_t BYTES = StuffedGeom<S>::BYTES;
+        const uint32_t t = threadIdx.x;
+        c0 = c0_;
+        n1 = min(nst, (uint32_t)SYNC_WG);   // chunks of the first kind (one per thread) ...
+        n2 = nst - n1;                      // ... and of the second (the look-ahead's, wavefront 0 only)
+        const uint64_t bA = (uint64_t)(c0 + t) * BYTES;
+        A.load(scan, n, bA, t < n1 && bA < n, prevA);
+        B.nb = B.nk = 0;
+        prevB = 0;
+        if (t < 64) {   // (wave-uniform)
+            const uint64_t bB = (uint64_t)(c0 + SYNC_WG + t) * BYTES;
+            B.load(scan, n, bB, t < n2 && bB < n, prevB);
+        }
+    }
+    __device__ __forceinline__ void finish(uint32_t* lds, uint32_t cap, uint32_t* start, uint32_t* red, uint32_t n)
+    {
+        constexpr uint32_t BYTES = StuffedGeom<S>::BYTES;
+        const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+        for (uint32_t j = t; j < cap; j += SYNC_WG) lds[j] = 0u;   // look-ahead past the end reads zero bits
+        A.flags(n, (uint64_t)(c0 + t) * BYTES, prevA);
+        uint32_t incA = A.nk, incB = 0;
+        if (t < 64) {
+            B.flags(n, (uint64_t)(c0 + SYNC_WG + t) * BYTES, prevB);
+            incB = B.nk;
+        }
+        // exclusive scans of the kept counts: the first kind over the workgroup, the second inside wavefront 0
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_up((int)incA, o);
+            if ((int)lane >= o) incA += x;
+        }
+        if (t < 64)
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)incB, o);
+                if ((int)lane >= o) incB += y;
+            }
+        if (lane == 63) red[wave] = incA;
+        __syncthreads();   // (also: the zero fill is done)
+        uint32_t base = 0, tot = 0;
+        for (uint32_t q = 0; q < SYNC_WG / 64; ++q) {
+            const uint32_t x = red[q];
+            if (q < wave) base += x;
+            tot += x;
+        }
+        uint8_t* lb = reinterpret_cast<uint8_t*>(lds);
+        const uint32_t posA = base + incA - A.nk, posB = tot + incB - B.nk;
+        if (t <= n1 && (t < n1 || n2 == 0)) start[t] = posA * 8;          // (t == n1 with no second kind: the end)
+        if (n2 && t <= n2 && t < 64) start[SYNC_WG + t] = posB * 8;        // (EXTRA <= 64; t == n2: the end)
+        if (t == 0 && n2 == 0 && n1 == (uint32_t)SYNC_WG) start[n1] = tot * 8;   // (the thread that would write the end does not exist)
+        A.scatter(lb, posA);
+        if (t < 64 && t < n2) B.scatter(lb, posB);
+        __syncthreads();
+    }
+};
+
 // Sequential reader: the next >= 32 bits sit MSB-aligned in a 64-bit register, so a symbol's
 // critical path is one LUT read, not LUT + two word fetches; the following word is fetched one
 // refill ahead.
@@ -964,6 +1111,9 @@ struct SyncArgs {
     unsigned long long spin_ticks;   // bound of the chained pass's wait for the predecessor (SpinGuard)
     uint32_t fault;     // test hook: bit 1 = workgroup 0 of a rippling chained pass never publishes
     uint32_t gray;      // one-component stream (extension): see run_count; the chroma blocks' bounds are preset to "exact"
+    const uint8_t* scan;   // non-null: no K0 ran -- the sub-sequences are chunks of the byte-stuffed scan (stage_unstuff), nsub = nsub_host
+    uint32_t scan_len;
+    uint32_t nsub_host;
 };
 constexpr uint64_t X_NONE = ~0ull;
 
@@ -983,13 +1133,13 @@ __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list,
 // launch (SYNC_WG threads; s = SYNC_WG int4 of LDS); also the call's bookkeeping: blocks found, passes
 // used, K0's look-back words cleared for the next call.
 template <int S, bool COUNT>
-__device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_t* status, int pass, bool rippling, unsigned long long* part,
+__device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_t nsub, uint32_t* status, int pass, bool rippling, unsigned long long* part,
                           uint32_t nparts, int4* s, int4* carry)
 {
     KPEG_GEOMETRY(S);
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (uint32_t i = t; i < nparts; i += SYNC_WG) part[i] = 0ull;
-    const uint32_t nw = (meta->nsub + OWN - 1) / OWN;
+    const uint32_t nw = (nsub + OWN - 1) / OWN;
     // s[0 .. SYNC_WG / 64): the wavefronts' totals; s[SYNC_WG / 64 ..): the same for the record counts (their .x)
     uint32_t* rc = reinterpret_cast<uint32_t*>(carry) + 1;   // (carry->x is read below: a word beside it)
     int4 run = make_int4(0, 0, 0, 0);     // totals of the chunks before this one (every thread keeps its own copy)
@@ -1078,6 +1228,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     __shared__ uint64_t s_wexit[SYNC_WG / 64];   // every wavefront's last exit state so far ...
     __shared__ uint32_t s_wdone[SYNC_WG / 64];   // ... and whether it is final
     __shared__ uint64_t s_edge[2];           // entry state of the first own item, exit state of the last
+    __shared__ uint32_t s_start[SYNC_WG + StuffedGeom<S>::EXTRA + 2];   // stuffed mode: first bit of every staged chunk in s_bits
     __shared__ uint32_t s_n[1];
     __shared__ int4 s_red[SYNC_WG / 64];
     __shared__ uint32_t s_redn[SYNC_WG / 64];
@@ -1086,12 +1237,13 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const int p = a.pass;
     uint32_t g = blockIdx.x;
     const uint32_t t = threadIdx.x;
-    const uint32_t nsub = a.meta->nsub, nseg = a.meta->nseg, n_u = a.meta->n_u;   // (one scalar load: the fields are neighbours)
+    const bool stuffed = a.scan != nullptr;
+    const uint32_t nsub = stuffed ? a.nsub_host : a.meta->nsub, nseg = stuffed ? 1u : a.meta->nseg, n_u = stuffed ? 0u : a.meta->n_u;
     // The last launch (chained) also scans the workgroup totals: at once by workgroup 0 if the pass
     // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
     const bool rippling = p >= 2 && a.meta->moved[p - 1] != 0;
     if (a.chained && !rippling) {
-        if (g == 0) wsum_scan<S, COUNT>(a.wsum, a.wrec, a.meta, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (g == 0) wsum_scan<S, COUNT>(a.wsum, a.wrec, a.meta, nsub, a.status, p, false, a.part, a.nparts, s_cnt, &s_red[0]);
         return;
     }
     if (a.chained) {
@@ -1111,7 +1263,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             s_n[0] = atomicAdd(&a.meta->ticket, 1u) == (nsub + OWN - 1) / OWN - 1 ? 1u : 0u;
         }
         __syncthreads();
-        if (s_n[0]) wsum_scan<S, COUNT>(a.wsum, a.wrec, a.meta, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
+        if (s_n[0]) wsum_scan<S, COUNT>(a.wsum, a.wrec, a.meta, nsub, a.status, p, true, a.part, a.nparts, s_cnt, &s_red[0]);
     };
     const uint64_t* Xb_prev = a.Xb + (size_t)((p & 1) ^ 1) * a.nwg_cap;
     uint64_t* Xb_cur = a.Xb + (size_t)(p & 1) * a.nwg_cap;
@@ -1156,17 +1308,35 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
 #if KPEG_SYNC_STATS
     const uint64_t tm0 = __builtin_amdgcn_s_memtime();
 #endif
-    load_tables(&T, a.tabs);
     const uint32_t nown = min((uint32_t)OWN, nsub - i0);
     const uint32_t wu = p == 0 ? min(a.warm, i0) : 0u;
     const uint32_t ibase = i0 - wu, nit = wu + nown;
+    StuffedStage<S> stg;
+    if (stuffed) stg.begin(a.scan, a.scan_len, ibase, nit + StuffedGeom<S>::EXTRA);   // (its loads fly while the tables load)
+    load_tables(&T, a.tabs);
     // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
-    const uint32_t w0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase).pstart >> 5;
-    {
+    uint32_t w0 = 0;
+    if (stuffed) {
+        stg.finish(s_bits, STAGE_CAP, s_start, s_redn, a.scan_len);
+    } else {
+        w0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase).pstart >> 5;
         const uint32_t total_words = (n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
     __syncthreads();
+    // stuffed mode: states that leave the workgroup carry virtual positions (chunk << VSHIFT | bit inside the chunk); the
+    // decode loops run on positions in s_bits.  An item's entry state lies in its own chunk, its exit state in the next one.
+    constexpr uint32_t VSHIFT = StuffedGeom<S>::VSHIFT;
+    auto to_local = [&](uint64_t v, uint32_t tl) -> DecState {
+        DecState d = unpack_state(v);
+        if (stuffed) d.p = s_start[tl] + (d.p & ((1u << VSHIFT) - 1u));
+        return d;
+    };
+    auto to_virtual = [&](uint64_t x, uint32_t tl) -> uint64_t {
+        if (!stuffed) return x;
+        const uint32_t pl = (uint32_t)x;
+        return (x & 0xFFFFFFFF00000000ull) | (uint64_t)(((ibase + tl + 1) << VSHIFT) | (pl - s_start[tl + 1]));
+    };
 
     // Every wavefront settles its 64 consecutive items on its own: no barrier, no work list.  An item's entry state
     // is its left neighbour's exit state -- one lane over (DPP shift), for lane 0 the last exit state of the
@@ -1190,7 +1360,15 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const uint64_t tm1 = __builtin_amdgcn_s_memtime();
 #endif
     if (have) {
-        const SubGeom geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase + t);
+        SubGeom geo;
+        if (stuffed) {
+            geo.seg = 0;
+            geo.li = ibase + t;
+            geo.pstart = s_start[t];
+            geo.pend = s_start[t + 1];
+        } else {
+            geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase + t);
+        }
         pend = geo.pend;
         segfirst = geo.li == 0;
         fixed = segfirst || (p == 0 && t == 0);
@@ -1200,8 +1378,13 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             s.c = 0;
             s.k = 0;
             s.q = 0;
-            used = pack_state(s);
+            {
+                DecState sv = s;
+                if (stuffed) sv.p = (ibase + t) << VSHIFT;
+                used = pack_state(sv);
+            }
             r = run_count<COUNT, false, S420>(T, s_bits, w0, s, pend, a.gray != 0);   // exit state only: see below
+            r.exit_state = to_virtual(r.exit_state, t);
 #if KPEG_SYNC_STATS
             st_runs++;
             st_iters += r.iters;
@@ -1285,7 +1468,8 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
                 continue;
             }
             if (again) {
-                r = run_count<COUNT, true, S420>(T, s_bits, w0, unpack_state(in), pend, a.gray != 0);
+                r = run_count<COUNT, true, S420>(T, s_bits, w0, to_local(in, t), pend, a.gray != 0);
+                r.exit_state = to_virtual(r.exit_state, t);
                 used = in;
 #if KPEG_SYNC_STATS
                 st_runs++;
@@ -1421,6 +1605,10 @@ struct WriteArgs {
     uint32_t* tile_start;    // [ntiles + 1], preset to 0 by K1
     uint32_t ntiles;
     uint32_t gray;           // one-component stream (extension, dense layout only): every block is block 0 of its MCU
+    const uint8_t* scan;     // non-null: no K0 ran -- the sub-sequences are chunks of the byte-stuffed scan (stage_unstuff), nsub = nsub_host
+    uint32_t scan_len;
+    uint32_t nsub_host;
+    EntropyMeta* meta_reset; // the call's last entropy kernel leaves K1's bookkeeping zero for the next call
 };
 constexpr uint32_t TILE_BLOCKS = 24;   // K4's tile: 8 MCUs x 3 components
 
@@ -1446,21 +1634,41 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     __shared__ uint32_t s_prer[COMPACT ? SYNC_WG : 1];   // scan of the record counts
     __shared__ int4 s_wred[SYNC_WG / 64];
     __shared__ uint32_t s_wredr[COMPACT ? SYNC_WG / 64 : 1];
+    __shared__ uint32_t s_wredr_st[SYNC_WG / 64 + 1];   // stage_unstuff's scratch
     constexpr uint32_t STAGE_CAP = SYNC_WG * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
     __shared__ uint32_t s_bits[STAGE_CAP];
-    const uint32_t nsub = a.meta->nsub, nseg = a.meta->nseg, n_u = a.meta->n_u;
+    __shared__ uint32_t s_start[SYNC_WG + StuffedGeom<S>::EXTRA + 2];   // stuffed mode: first bit of every staged chunk in s_bits
+    const bool stuffed = a.scan != nullptr;
+    const uint32_t nsub = stuffed ? a.nsub_host : a.meta->nsub, nseg = stuffed ? 1u : a.meta->nseg, n_u = stuffed ? 0u : a.meta->n_u;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.meta_reset) {
+        // K1 is over (this kernel follows its last launch): its per-call bookkeeping back to zero -- K0 does this when it runs,
+        // nothing else would for a call without K0
+        for (int q = 0; q < SYNC_PASSES + 8; ++q) a.meta_reset->moved[q] = 0;
+        a.meta_reset->ticket = 0;
+        a.meta_reset->k1_order = 0;
+    }
     const uint32_t i0 = blockIdx.x * OWN;
     if (i0 >= nsub) return;
 #if KPEG_SYNC_STATS
     const uint64_t tw0 = __builtin_amdgcn_s_memtime();
     uint32_t st_steps = 0;
 #endif
+    StuffedStage<S> stg;
+    if (stuffed) stg.begin(a.scan, a.scan_len, i0, min((uint32_t)OWN, nsub - i0) + StuffedGeom<S>::EXTRA);   // (its loads fly while the tables load)
     load_tables(&T, a.tabs);
     const uint32_t i = i0 + threadIdx.x;
     const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
-    const SubGeom g0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i0);
-    const uint32_t w0 = g0.pstart >> 5;
-    {
+    SubGeom g0;
+    uint32_t w0 = 0;
+    if (stuffed) {
+        stg.finish(s_bits, STAGE_CAP, s_start, s_wredr_st, a.scan_len);
+        g0.seg = 0;
+        g0.li = i0;
+        g0.pstart = 0;
+        g0.pend = 0;
+    } else {
+        g0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i0);
+        w0 = g0.pstart >> 5;
         const uint32_t total_words = (n_u + 3) / 4 + 2;
         stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
     }
@@ -1539,7 +1747,15 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
     int4 pre = make_int4(0, 0, 0, 0);
     if (valid) {
-        const SubGeom g = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i);
+        SubGeom g;
+        if (stuffed) {
+            g.seg = 0;
+            g.li = i;
+            g.pstart = s_start[threadIdx.x];
+            g.pend = s_start[threadIdx.x + 1];
+        } else {
+            g = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i);
+        }
         DecState s;
         if (g.li == 0) {
             s.p = g.pstart;
@@ -1548,9 +1764,10 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             s.q = 0;
         } else {
             s = unpack_state(a.X[i - 1]);
+            if (stuffed) s.p = g.pstart + (s.p & ((1u << StuffedGeom<S>::VSHIFT) - 1u));   // virtual position: it lies in this lane's chunk
         }
         // block index and DC predictors at entry, relative to the segment start
-        const uint32_t first = a.sub_base[g.seg];
+        const uint32_t first = stuffed ? 0u : a.sub_base[g.seg];
         if (g.li != 0) {
             const int4 loc = s_pre[threadIdx.x];
             if (nseg == 1) {
@@ -1738,7 +1955,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         // reference ignores them: a later lane never gets here)
         if (COMPACT && (fl & FL_LAST) && g.seg + 1 == nseg) a.tile_start[a.ntiles] = ord;
         // the last sub-sequence of a segment must have produced the segment's last block, all of it
-        if (g.li + 1 == a.sub_base[g.seg + 1] - first) {
+        if (g.li + 1 == (stuffed ? nsub : a.sub_base[g.seg + 1] - first)) {
             if (b < blk_limit) err |= 128;
             if (k != 0 && b >= 1 && b - 1 < blk_limit) err |= 64;   // (bits after the segment's last block are ignored, as the reference ignores them)
         }
@@ -1909,11 +2126,18 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     bt.len_tab = L.d_len_tab;
     bt.wg_tab = L.d_wg_tab;
 
-    if (!S->part_clean) ENT_HIP(hipMemsetAsync(S->d_part, 0, S->part_cap, L.stream));
-    S->part_clean = false;
-    hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, markers, (unsigned long long*)S->d_part,
-                       (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt, nseg_expected, (uint32_t)SUBSEQ_BITS,
-                       L.spin_ticks ? L.spin_ticks : K0_SPIN_TICKS, L.fault);
+    // One image without restart markers needs no K0: the sub-sequences are chunks of the scan as it is, and the workgroups of
+    // K1 and K2 un-stuff what they stage (stage_unstuff).  Restart segments and batches keep K0: it finds the markers and
+    // lays the segments out.
+    const bool stuffed = !L.nimg && !rst && !L.force_k0 && n > 0;
+    const uint32_t nsub_host = (uint32_t)(((uint64_t)n + SUBSEQ_BITS / 8 - 1) / (SUBSEQ_BITS / 8));
+    if (!stuffed) {
+        if (!S->part_clean) ENT_HIP(hipMemsetAsync(S->d_part, 0, S->part_cap, L.stream));
+        S->part_clean = false;
+        hipLaunchKernelGGL(k_unstuff, dim3(nparts), dim3(US_THREADS), 0, L.stream, L.d_scan, n, markers, (unsigned long long*)S->d_part,
+                           (uint8_t*)S->d_u, seg_off, seg_cap, S->d_meta, sub_base, nsub_cap, L.d_status, bt, nseg_expected, (uint32_t)SUBSEQ_BITS,
+                           L.spin_ticks ? L.spin_ticks : K0_SPIN_TICKS, L.fault);
+    }
     mark(1);
 
     SyncArgs sa;
@@ -1943,9 +2167,12 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.spin_ticks = L.spin_ticks ? L.spin_ticks : K1_SPIN_TICKS;
     sa.fault = L.fault;
     sa.gray = L.gray;
+    sa.scan = stuffed ? L.d_scan : nullptr;
+    sa.scan_len = n;
+    sa.nsub_host = nsub_host;
     const int npass = L.sync_passes >= 3 ? L.sync_passes : SYNC_PASSES;   // the last one is chained and runs the scan
     sa.part = (unsigned long long*)S->d_part;
-    sa.nparts = nparts;
+    sa.nparts = stuffed ? 0u : nparts;   // (K0's look-back words: untouched without K0)
     for (int t = 0; t < npass; ++t) {
         sa.pass = t;
         sa.chained = t == npass - 1 ? 1 : 0;
@@ -1981,13 +2208,17 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     wa.tile_start = L.d_tile_start;
     wa.ntiles = L.ntiles;
     wa.gray = L.gray;
+    wa.scan = sa.scan;
+    wa.scan_len = n;
+    wa.nsub_host = nsub_host;
+    wa.meta_reset = S->d_meta;
     if (L.sub420) hipLaunchKernelGGL((k_write<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else hipLaunchKernelGGL((k_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);
     mark(5);
     ENT_HIP(hipGetLastError());
-    S->part_clean = true;   // K1's last launch is enqueued
+    if (!stuffed) S->part_clean = true;   // K1's last launch is enqueued
     return KPEG_HIP_OK;
 #undef ENT_HIP
 }

@@ -47,6 +47,7 @@ struct kpeg_hip_ctx {
     size_t scan_cap = 0;
     void* d_rgb = nullptr;
     size_t rgb_cap = 0;
+    uint32_t force_k0 = 0;      // debug key 8 / KPEG_FORCE_K0
     void* d_pad = nullptr;      // any-size extension: the padded picture K4 writes before the crop
     size_t pad_cap = 0;
     void* d_ebound = nullptr;  // per-block error bounds for K4 (written by K2 or k_ebound)
@@ -189,6 +190,7 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
             const int v = std::atoi(s);
             if (v > 0) ctx->k4_wgs_per_cu = v;
         }
+        if (const char* s = std::getenv("KPEG_FORCE_K0")) ctx->force_k0 = std::atoi(s) ? 1u : 0u;
         if (const char* s = std::getenv("KPEG_COEF_LAYOUT")) ctx->coef_layout = std::atoi(s);   // experiments: as kpeg_hip_debug_set key 7
         if (std::getenv("KPEG_DEBUG")) std::fprintf(stderr, "kpeg_hip: K4 workgroups per CU: %d (occupancy query %d), %d wavefronts each\n", ctx->k4_wgs_per_cu, nb, K4_WAVES);
     }
@@ -541,6 +543,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.subseq = ctx->subseq;
     L.gray = f->components == 1 ? 1u : 0u;
     L.sub420 = sub420 ? 1u : 0u;
+    L.force_k0 = ctx->force_k0;
     if (compact) {
         // a record takes at least two bits of the stream (a one-bit code and a one-bit magnitude), a block holds at most 63
         const uint64_t bytes = batch ? batch->total_len : (uint64_t)scan_len;
@@ -1157,6 +1160,7 @@ extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
     else if (key == 5) ctx->spin_ticks = value > 0 ? (unsigned long long)value * 100ull : 0ull;   // microseconds
     else if (key == 6) ctx->fault = (uint32_t)value;
     else if (key == 7) ctx->coef_layout = value;
+    else if (key == 8) ctx->force_k0 = value ? 1u : 0u;   // K0 even for one image without restart markers (K1 and K2 un-stuff for themselves there)
     else return KPEG_HIP_E_ARG;
     return KPEG_HIP_OK;
 }

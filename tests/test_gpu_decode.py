@@ -382,18 +382,77 @@ def test_full_size_8k_properties(ctx):
 
 @pytest.mark.parametrize("offset", [1, 7])
 def test_unaligned_scan_pointer(ctx, offset):
-    """K0 loads 16 bytes per thread when the scan pointer allows it and falls back to bytes when not."""
+    """The scan pointer has any alignment.  K0 (kept for restart segments and batches; forced here with debug key 8) loads
+    16 bytes per thread when the pointer allows it and falls back to bytes when not; without K0 the workgroups of K1 and
+    K2 un-stuff the chunks they stage and load them as aligned words around the chunk."""
     import torch
     data = T.synth_jpeg(512, 256, seed=91, restart_interval=0)
     st, want = T.oracle_decode(data)
     p = T.oracle_parse(data)
     buf = torch.zeros(len(p.scan) + 64, dtype=torch.uint8, device="cuda")
     buf[offset:offset + len(p.scan)] = torch.frombuffer(bytearray(p.scan), dtype=torch.uint8).cuda()
-    d_rgb = torch.empty((256, 512, 3), dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    ctx.decode_scan_dev(T.make_frame(p), buf.data_ptr() + offset, len(p.scan), d_rgb.data_ptr())
-    ctx.sync()
-    assert np.array_equal(d_rgb.cpu().numpy(), want)
+    try:
+        for k0 in (0, 1):
+            assert ctx.lib.kpeg_hip_debug_set(ctx._h, 8, k0) == 0
+            d_rgb = torch.zeros((256, 512, 3), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctx.decode_scan_dev(T.make_frame(p), buf.data_ptr() + offset, len(p.scan), d_rgb.data_ptr())
+            ctx.sync()
+            assert np.array_equal(d_rgb.cpu().numpy(), want), k0
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 8, 0)
+
+
+@pytest.mark.parametrize("w,h,q,sigma,smode", [(8, 8, 75, 6.0, 0), (16, 8, 90, 6.0, 0), (64, 64, 95, 0.0, 1), (712, 472, 95, 0.0, 1),
+                                               (1920, 1080, 98, 40.0, 0), (3840, 2160, 75, 6.0, 0)])
+def test_with_and_without_k0(ctx, w, h, q, sigma, smode):
+    """One image without restart markers is decoded without K0: K1's and K2's workgroups un-stuff the 12-byte (48-byte)
+    chunks of the scan they stage, positions that leave a workgroup are chunk << 7 | bit.  Same pixels as with K0 (debug
+    key 8) and as the oracle: scans of one chunk, dense noise (an FF 00 every few chunks: chunks of every length from 6 to
+    12 bytes, stuffing on chunk and workgroup boundaries), both sub-sequence sizes, both coefficient layouts."""
+    data = T.synth_jpeg(w, h, seed=5 + w, quality=q, sigma=sigma, mode=smode)
+    st, want = T.oracle_decode(data, 16)
+    assert st == T.DECODE_DONE
+    p = T.oracle_parse(data)
+    assert w < 64 or p.scan.count(b"\xff\x00") > 3
+    frame = T.make_frame(p)
+    try:
+        for k0 in (0, 1):
+            for layout in (1, 2):
+                assert ctx.lib.kpeg_hip_debug_set(ctx._h, 8, k0) == 0 and ctx.lib.kpeg_hip_debug_set(ctx._h, 7, layout) == 0
+                got = ctx.decode_scan(frame, p.scan)
+                bad = np.argwhere(got != want)
+                assert bad.size == 0, "K0 %d layout %d: first mismatches (y,x,c) %s of %d" % (k0, layout, bad[:8].tolist(), len(bad))
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 8, 0)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+
+
+def test_stuffing_at_the_very_end_without_k0(ctx):
+    """byteStuffScanData's tail rule (Decoder.cpp:631-650: a 00 after an FF stays if it is the scan's last byte) in the
+    last chunk of the last workgroup: the committed fixture the real reference decoded, and scans cut so that they end in
+    FF 00 / FF / 00."""
+    import os
+    import libkpeg_amd as K
+    for name in ("ok_trailing_ff", "ok_no_eoi", "ok_comment"):
+        data = open(os.path.join(T.GOLDEN, name + ".jpg"), "rb").read()
+        st, want = T.oracle_decode(data)
+        assert st == T.DECODE_DONE
+        rc, frame, scan = K.host_parse(data)
+        for k0 in (0, 1):
+            ctx.lib.kpeg_hip_debug_set(ctx._h, 8, k0)
+            assert np.array_equal(ctx.decode_scan(frame, scan), want), (name, k0)
+    ctx.lib.kpeg_hip_debug_set(ctx._h, 8, 0)
+    # the same stream with 1..3 bytes of FF / 00 appended (bits after the last block are ignored, as the reference ignores them)
+    data = T.synth_jpeg(128, 64, seed=12, sigma=20.0)
+    st, want = T.oracle_decode(data)
+    p = T.oracle_parse(data)
+    frame = T.make_frame(p)
+    for tail in (b"\xff\x00", b"\xff", b"\x00", b"\xff\x00\xff\x00", b"\xff\x00\x00"):
+        for k0 in (0, 1):
+            ctx.lib.kpeg_hip_debug_set(ctx._h, 8, k0)
+            assert np.array_equal(ctx.decode_scan(frame, p.scan + tail), want), (tail, k0)
+    ctx.lib.kpeg_hip_debug_set(ctx._h, 8, 0)
 
 
 def test_decode_batch(ctx):
