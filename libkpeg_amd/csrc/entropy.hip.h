@@ -1653,11 +1653,17 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const uint64_t tw0 = __builtin_amdgcn_s_memtime();
     uint32_t st_steps = 0;
 #endif
+    const uint32_t i = i0 + threadIdx.x;
+    const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
+    // everything this lane needs from K1, asked for before the tables and the slice are (one memory latency, not three)
+    const int4 cnt_i = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
+    const uint32_t nrec_i = COMPACT && valid ? a.nrec[i] : 0u;
+    const uint64_t x_prev = valid && i > 0 ? a.X[i - 1] : 0ull;
+    const int4 wsum_g = a.wsum[blockIdx.x];
+    const uint32_t wrec_g = COMPACT ? a.wrec[blockIdx.x] : 0u;
     StuffedStage<S> stg;
     if (stuffed) stg.begin(a.scan, a.scan_len, i0, min((uint32_t)OWN, nsub - i0) + StuffedGeom<S>::EXTRA);   // (its loads fly while the tables load)
     load_tables(&T, a.tabs);
-    const uint32_t i = i0 + threadIdx.x;
-    const bool valid = threadIdx.x < OWN && i < nsub;   // K1's partition: OWN sub-sequences per workgroup
     SubGeom g0;
     uint32_t w0 = 0;
     if (stuffed) {
@@ -1679,8 +1685,8 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup (inside the wavefronts by
     // shuffles, their totals through LDS: one barrier instead of the twenty of a scan that lives in LDS) ...
     {
-        const int4 v = valid ? a.cnt[i] : make_int4(0, 0, 0, 0);
-        const uint32_t vr = COMPACT && valid ? a.nrec[i] : 0u;
+        const int4 v = cnt_i;
+        const uint32_t vr = nrec_i;
         int4 inc = v;
         uint32_t incr = vr;
         const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1763,7 +1769,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             s.k = 0;
             s.q = 0;
         } else {
-            s = unpack_state(a.X[i - 1]);
+            s = unpack_state(x_prev);
             if (stuffed) s.p = g.pstart + (s.p & ((1u << StuffedGeom<S>::VSHIFT) - 1u));   // virtual position: it lies in this lane's chunk
         }
         // block index and DC predictors at entry, relative to the segment start
@@ -1771,12 +1777,12 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         if (g.li != 0) {
             const int4 loc = s_pre[threadIdx.x];
             if (nseg == 1) {
-                pre = add4(a.wsum[blockIdx.x], loc);
+                pre = add4(wsum_g, loc);
             } else if (first >= i0) {
                 const int4 f = s_pre[first - i0];
                 pre = make_int4(loc.x - f.x, loc.y - f.y, loc.z - f.z, loc.w - f.w);
             } else {
-                const int4 w = a.wsum[blockIdx.x];
+                const int4 w = wsum_g;
                 pre = make_int4(w.x + loc.x - open_base.x, w.y + loc.y - open_base.y, w.z + loc.z - open_base.z, w.w + loc.w - open_base.w);
             }
         }
@@ -1817,8 +1823,8 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         // which block of which K4 tile the next block to start is (global block gbase + b = 24 tile + bmn)
         uint32_t ord = 0, ord_end = 0, bmn = 0, tn = 0, bm_cur = 0;
         if (COMPACT) {
-            ord = a.wrec[blockIdx.x] + s_prer[threadIdx.x];
-            ord_end = min(ord + a.nrec[i], a.rec_cap);
+            ord = wrec_g + s_prer[threadIdx.x];
+            ord_end = min(ord + nrec_i, a.rec_cap);
             const uint32_t gbn = seg_mcu0 * 3 + b;
             tn = gbn / TILE_BLOCKS;
             bmn = gbn - tn * TILE_BLOCKS;
