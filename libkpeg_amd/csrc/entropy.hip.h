@@ -1752,8 +1752,12 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     int tail_chroma = 0;
     constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
     int4 pre = make_int4(0, 0, 0, 0);
+    SubGeom g;
+    g.seg = g.li = g.pstart = g.pend = 0;
+    DecState s;
+    s.p = s.c = s.k = s.q = 0;
+    uint32_t first = 0;
     if (valid) {
-        SubGeom g;
         if (stuffed) {
             g.seg = 0;
             g.li = i;
@@ -1762,7 +1766,6 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         } else {
             g = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i);
         }
-        DecState s;
         if (g.li == 0) {
             s.p = g.pstart;
             s.c = 0;
@@ -1773,7 +1776,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             if (stuffed) s.p = g.pstart + (s.p & ((1u << StuffedGeom<S>::VSHIFT) - 1u));   // virtual position: it lies in this lane's chunk
         }
         // block index and DC predictors at entry, relative to the segment start
-        const uint32_t first = stuffed ? 0u : a.sub_base[g.seg];
+        first = stuffed ? 0u : a.sub_base[g.seg];
         if (g.li != 0) {
             const int4 loc = s_pre[threadIdx.x];
             if (nseg == 1) {
@@ -1786,6 +1789,12 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
                 pre = make_int4(w.x + loc.x - open_base.x, w.y + loc.y - open_base.y, w.z + loc.z - open_base.z, w.w + loc.w - open_base.w);
             }
         }
+    }
+    // Everybody has read the scan's values: until the shares go there after the loop, a lane's s_pre slot is its ring of four
+    // records (compact stream) -- records leave as one aligned 16-byte store per four instead of four 4-byte stores, a quarter
+    // of the store instructions and of the cache-line requests behind them.
+    __syncthreads();
+    if (valid) {
         const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
         const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
         const bool gray = !COMPACT && !S420 && a.gray != 0;     // one block per MCU, stored as the MCU's luma block (stride 3); dense layout only
@@ -1822,6 +1831,8 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         // compact stream: where this lane's records go (K1 counted them: the scan gives every lane its first ordinal), and
         // which block of which K4 tile the next block to start is (global block gbase + b = 24 tile + bmn)
         uint32_t ord = 0, ord_end = 0, bmn = 0, tn = 0, bm_cur = 0;
+        uint32_t nq = 0;                     // records in the ring
+        uint32_t* const ring = reinterpret_cast<uint32_t*>(&s_pre[threadIdx.x]);
         if (COMPACT) {
             ord = wrec_g + s_prer[threadIdx.x];
             ord_end = min(ord + nrec_i, a.rec_cap);
@@ -1910,8 +1921,22 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
                 const uint32_t zw = __float_as_uint(zm.y);
                 if (COMPACT) {
                     if (ord < ord_end) {   // (always: K1 counted by the same rule)
-                        a.rec[ord] = ((uint32_t)ext << 16) | (zw & 0x3F00u) | bm_cur;
+                        ring[nq] = ((uint32_t)ext << 16) | (zw & 0x3F00u) | bm_cur;
+                        nq++;
                         ord++;
+                        if ((ord & 3u) == 0) {
+                            // a 16-byte boundary of the record array: the ring goes (whole: one store; a lane's first, shorter run: singly)
+                            const uint4 v = *reinterpret_cast<const uint4*>(ring);
+                            if (nq == 4) {
+                                *reinterpret_cast<uint4*>(a.rec + (ord - 4)) = v;
+                            } else {
+                                uint32_t* d = a.rec + (ord - nq);
+                                d[0] = v.x;
+                                if (nq > 1) d[1] = v.y;
+                                if (nq > 2) d[2] = v.z;
+                            }
+                            nq = 0;
+                        }
                     }
                 } else {
                     a.coef[((size_t)gb << 6) | ((zw >> 8) & 63u)] = (int16_t)ext;
@@ -1944,6 +1969,13 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
                 nnz = 0;
                 ncw = 0;
             }
+        }
+        if (COMPACT && nq) {   // what is left in the ring (fewer than four)
+            const uint4 v = *reinterpret_cast<const uint4*>(ring);
+            uint32_t* d = a.rec + (ord - nq);
+            d[0] = v.x;
+            if (nq > 1) d[1] = v.y;
+            if (nq > 2) d[2] = v.z;
         }
         if (ebits & E_BAD) err |= 8;
         if (ebits & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
