@@ -7,29 +7,35 @@
 //
 // A baseline scan without restart markers is one serial bit string, so the decode is the
 // two-pass "self-synchronising sub-sequence" scheme:
-//   K0  unstuff   byte-parallel removal of the 00 after FF (reference rule incl. its tail
-//                 rule) and, with DRI, of the RSTn markers; compaction by decoupled look-back,
-//                 one launch.  Output is the bit string as big-endian 32-bit words +
-//                 restart-segment offsets (the images of a fused batch are such segments).
-//   K1  sync      one item per sub-sequence of SUBSEQ_BITS bits: decode from a guessed
-//                 codeword boundary, then rounds of "re-decode from my predecessor's exit
-//                 state" for exactly the items whose predecessor moved (a compacted work
-//                 list: Huffman streams re-synchronise after a few symbols, so the list
-//                 shrinks geometrically).  A workgroup also decodes the last WARM
+//   (stage)       one image without restart markers needs no kernel for it: the sub-sequences are chunks of
+//                 SUBSEQ_BITS / 8 bytes of the scan as it is, and the workgroups of K1 and K2 remove the 00 after FF
+//                 (reference rule incl. its tail rule) from the chunks they stage, while they stage them
+//                 (stage_unstuff; positions that leave a workgroup are chunk << 7 | bit).
+//   K0  unstuff   restart segments and batches: byte-parallel removal of the 00 after FF and, with DRI, of the
+//                 RSTn markers; compaction by decoupled look-back, one launch.  Output is the bit string as
+//                 big-endian 32-bit words + restart-segment offsets (the images of a fused batch are such segments).
+//   K1  sync      one item per sub-sequence, one per thread: decode from a guessed codeword boundary (exit state
+//                 only), then every wavefront settles its 64 consecutive items on its own -- an item decodes again
+//                 exactly when its left neighbour's exit state differs from the state it last decoded from (Huffman
+//                 streams re-synchronise after a few symbols: 2.2 decodes per item), no barrier, no work list.
+//                 A workgroup also decodes the last WARM
 //                 sub-sequences of its predecessor, which gives it its own entry state
 //                 without waiting for the predecessor; pass 1 verifies that assumption against
 //                 the predecessor's real exit state and only a workgroup that guessed wrong
 //                 decodes again.  The first sub-sequence of every restart segment starts from
-//                 a known state.  Each run also counts the blocks it starts and sums their DC
-//                 differences.  Pass 0 clears the coefficient buffer in the background.  The
+//                 a known state.  Each counted run also counts the blocks it starts, sums their DC
+//                 differences and (compact stream) counts the records K2 will write.  Pass 0 clears the dense
+//                 coefficient buffer in the background.  The
 //                 third and last launch is chained (every workgroup waits for its predecessor's
 //                 published state) if pass 1 still moved something -- no stream is given up --
 //                 and in any case runs the
-//       scan      exclusive prefix sum of (blocks, dc[3]) over the workgroups: with K2's local
-//                 scan, absolute block index and DC predictors at every sub-sequence entry.
+//       scan      exclusive prefix sum of (blocks, dc[3], records) over the workgroups: with K2's local
+//                 scan, absolute block index, DC predictors and record ordinal at every sub-sequence entry.
 //   K2  write     one lane per sub-sequence decodes its own symbols again from its true entry
-//                 state and scatters the non-zero coefficients into the cleared buffer (natural
-//                 order, absolute DC, quirk Q1 applied) -- the layout K4 reads -- plus K4's
+//                 state and writes what K4 reads -- the non-zero coefficients scattered into the cleared dense
+//                 buffer (natural order, absolute DC, quirk Q1 applied), or, compact stream, a 4-byte record per
+//                 non-zero AC coefficient at the lane's next ordinal (four at a time through a ring in LDS) + the
+//                 blocks' DC values + every tile's first record -- plus K4's
 //                 per-block error bound (blocks split over lanes or workgroups are settled by
 //                 the side that holds their end).
 // The decode loops are bound by the instruction count of one symbol step (a wavefront runs
@@ -49,11 +55,8 @@
 
 namespace kpeg_dev {
 
-#ifndef KPEG_ABLATE_W
-#define KPEG_ABLATE_W 0   // timing experiments only (tools/variants.sh)
-#endif
 #ifndef KPEG_SYNC_STATS
-#define KPEG_SYNC_STATS 0   // 1: loop counts into status words 8..13 (tools/sync_dbg.py)
+#define KPEG_SYNC_STATS 0   // 1: per-wavefront timelines of K1's pass 0 and of K2 into g_ent_stamp (tools/sync_dbg.py)
 #endif
 #ifndef KPEG_SUBSEQ_BITS
 #define KPEG_SUBSEQ_BITS 96
