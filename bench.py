@@ -185,6 +185,24 @@ def bench_batch(args, torch, K):
         dt = (time.perf_counter() - t0) / args.steps
         ctx.sync()
         res[name] = dt
+        if name == "lanes":
+            # the pixels of the timed batch against libKPEG's own decoder (tests/golden/manifest_large.json): the distinct
+            # images by SHA-256, every repeat against its first copy on the device
+            import hashlib
+            mf = os.path.join(ROOT, "tests", "golden", "manifest_large.json")
+            man = json.load(open(mf)).get("synth", {}) if os.path.exists(mf) else {}
+            verified = True
+            for i in range(uniq):
+                g = man.get("%dx%d_seed%d" % (w, h, SEED + i))
+                if not g or (g["quality"], g["sigma"]) != (QUALITY, SIGMA):
+                    verified = None
+                    break
+                if hashlib.sha256(d_rgbs[i].cpu().numpy().tobytes()).hexdigest() != g["rgb_sha256"]:
+                    raise SystemExit("bench.py --batch: image %d differs from the reference's pixels (SHA-256 mismatch)" % i)
+            if verified:
+                for i in range(uniq, n):
+                    if not torch.equal(d_rgbs[i], d_rgbs[i % uniq]):
+                        raise SystemExit("bench.py --batch: image %d differs from its first copy" % i)
     mp = n * w * h / 1e6
     print(json.dumps({
         "metric": "Mpixels/s decoded (JFIF->RGB), batch of 1080p 4:4:4 baseline", "value": round(mp / res["lanes"], 2), "unit": "Mpixels/s",
@@ -192,7 +210,7 @@ def bench_batch(args, torch, K):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "batch of %d synthetic 1920x1080 4:4:4 baseline JPEGs q%d (%d distinct, seeds %d..), resident in HBM, "
                                "kpeg_hip_decode_batch_dev (the batch as restart segments of one virtual stream: one set of launches)" % (n, QUALITY, uniq, SEED), "images_per_step": n},
-        "images_per_s": round(n / res["lanes"], 1), "us_per_image": round(res["lanes"] / n * 1e6, 2),
+        "verified": verified, "images_per_s": round(n / res["lanes"], 1), "us_per_image": round(res["lanes"] / n * 1e6, 2),
         "one_stream": {"value": round(mp / res["one_stream"], 2), "us_per_image": round(res["one_stream"] / n * 1e6, 2)},
     }), flush=True)
 
