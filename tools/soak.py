@@ -43,6 +43,8 @@ def main():
                 ctx.lib.kpeg_hip_debug_set(ctx._h, 7, int(rng.choice([0, 1, 2])))
             else:
                 w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+                if kind == "gray":      # the grayscale oracle wants whole blocks
+                    w, h = ((w + 7) & ~7), ((h + 7) & ~7)
                 y, x = np.mgrid[0:h, 0:w]
                 px = np.stack([(x * 3 + y) % 256, (y * 2) % 256, (x + y * 5) % 256], -1) * float(rng.random()) + rng.normal(128, float(rng.choice([1, 10, 40])), (h, w, 3)) * float(rng.random())
                 px = np.clip(px, 0, 255).astype(np.uint8)
