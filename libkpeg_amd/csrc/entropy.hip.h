@@ -137,6 +137,10 @@ struct EntropyTables {  // built on the host per frame, copied to the device whe
     float2 zzm[2][64];               // K2's one read per coefficient: .x = mscale_zz, .y (bits) = natural position << 8 | outside the 2x2 corner << 31
     float q00[2];                    // Q[0][0] of both tables
     float pad16[2];                  // (the tables are copied to LDS in 16-byte pieces)
+    // K1's exit-state decodes only (run_exit): the AC tables again, [id], with TWO symbols per entry wherever the second
+    // symbol's code still lies inside the LUT_BITS window.  Same fields: bits used = both symbols', coefficient advance = the
+    // sum (an EOB's 64 included).  Only looked up while k < 48, where the first symbol (advance <= 16) cannot end the block.
+    uint32_t lutx[2][1 << LUT_BITS];
 };
 
 static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
@@ -203,8 +207,46 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
             }
             if (k == 0) return -1;
         }
+    for (int id = 0; id < 2; ++id)
+        for (int j = 0; j < (1 << LUT_BITS); ++j) {
+            const uint32_t e1 = t->lut[2 + id][j];
+            uint32_t x = e1;
+            const uint32_t len1 = e1 & 31;
+            if (!(e1 & (E_LONG | E_BAD | E_ZERO)) && (e1 & E_ACSYM) && len1 < (uint32_t)LUT_BITS) {
+                const uint32_t room = LUT_BITS - len1;
+                const uint32_t e2 = t->lut[2 + id][(j << len1) & ((1 << LUT_BITS) - 1)];
+                if (!(e2 & (E_LONG | E_BAD)) && ((e2 >> 5) & 31) <= room)
+                    x = (len1 + (e2 & 31)) | ((((e1 >> 16) & 127) + ((e2 >> 16) & 127)) << 16);
+            }
+            t->lutx[id][j] = x;
+        }
     return 0;
 }
+
+// Cross-lane moves inside the VALU (DPP) instead of through the LDS crossbar (ds_bpermute, which is what __shfl_* become):
+// a scan step is then one add, not a round trip of a hundred cycles -- it matters where one wavefront works alone.
+// All 64 lanes must be active.  Lanes a DPP control does not write read 0 (old = 0, bound_ctrl off).
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int dpp0(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// inclusive prefix sum over the wavefront (lane 63 ends with the total)
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    int s = x;
+    s += dpp0<0x111>(x);               // row_shr:1
+    s += dpp0<0x112>(x);               // row_shr:2
+    s += dpp0<0x113>(x);               // row_shr:3: four terms, inside every row of 16
+    s += dpp0<0x114, 0xF, 0xE>(s);     // row_shr:4 into lanes 4..15 of the rows
+    s += dpp0<0x118, 0xF, 0xC>(s);     // row_shr:8 into lanes 8..15
+    s += dpp0<0x142, 0xA, 0xF>(s);     // row_bcast:15: rows 1 and 3 take the total of the row before
+    s += dpp0<0x143, 0xC, 0xF>(s);     // row_bcast:31: rows 2 and 3 take the total of rows 0..1
+    return s;
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) { return (uint32_t)wave_scan_incl((int)x); }
+// the value of the lane before (lane 0: 0)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) { return (uint32_t)dpp0<0x138>((int)x); }   // wave_shr:1
 
 struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t n_u;      // un-stuffed length in bytes
@@ -698,7 +740,7 @@ struct LdsTables {
     float q00[2];
     float pad16[2];
 };
-static_assert(sizeof(LdsTables) - sizeof(uint32_t) * 6 * (1 << LUT_BITS) == sizeof(EntropyTables) - sizeof(uint32_t) * 4 * (1 << LUT_BITS),
+static_assert(sizeof(LdsTables) - sizeof(uint32_t) * 6 * (1 << LUT_BITS) == offsetof(EntropyTables, lutx) - sizeof(uint32_t) * 4 * (1 << LUT_BITS),
               "layout after the first-level tables");
 
 __device__ __forceinline__ uint32_t slot_table(uint32_t slot) { return (slot & 1) * 2 + (slot >= 2 ? 1 : 0); }  // [class*2+id]
@@ -712,12 +754,23 @@ __device__ __forceinline__ void load_tables(LdsTables* dst, const EntropyTables*
         const uint32_t slot = i / LUT_V4;
         l[i] = reinterpret_cast<const uint4*>(&src->lut[slot_table(slot)][0])[i - slot * LUT_V4];
     }
-    constexpr uint32_t nbytes = sizeof(EntropyTables) - sizeof(uint32_t) * 4 * (1 << LUT_BITS);
+    constexpr uint32_t nbytes = offsetof(EntropyTables, lutx) - sizeof(uint32_t) * 4 * (1 << LUT_BITS);
     static_assert(nbytes % 16 == 0 && (sizeof(uint32_t) * 4 * (1 << LUT_BITS)) % 16 == 0 && (sizeof(uint32_t) * 6 * (1 << LUT_BITS)) % 16 == 0,
                   "tables are copied in 16-byte pieces");
     const uint4* s = reinterpret_cast<const uint4*>(&src->pool[0][0]);
     uint4* d = reinterpret_cast<uint4*>(&dst->pool[0][0]);
     for (uint32_t i = threadIdx.x; i < nbytes / 16; i += blockDim.x) d[i] = s[i];
+}
+// K1: the six slots once more, the AC slots with the two-symbol entries (the DC slots as they are: one base for all lookups)
+__device__ __forceinline__ void load_tables_x(uint32_t* dst, const EntropyTables* src)
+{
+    constexpr uint32_t LUT_V4 = (1u << LUT_BITS) / 4;
+    uint4* l = reinterpret_cast<uint4*>(dst);
+    for (uint32_t i = threadIdx.x; i < 6 * LUT_V4; i += blockDim.x) {
+        const uint32_t slot = i / LUT_V4;
+        const uint32_t* tab = (slot & 1) ? &src->lutx[slot >= 2 ? 1 : 0][0] : &src->lut[slot_table(slot)][0];
+        l[i] = reinterpret_cast<const uint4*>(tab)[i - slot * LUT_V4];
+    }
 }
 
 // The bit string as the decode loops see it: the workgroup's slice staged in LDS.  Every position
@@ -849,15 +902,8 @@ struct StuffedStage {
             incB = B.nk;
         }
         // exclusive scans of the kept counts: the first kind over the workgroup, the second inside wavefront 0
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t x = (uint32_t)__shfl_up((int)incA, o);
-            if ((int)lane >= o) incA += x;
-        }
-        if (t < 64)
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t y = (uint32_t)__shfl_up((int)incB, o);
-                if ((int)lane >= o) incB += y;
-            }
+        incA = wave_scan_incl(incA);
+        if (t < 64) incB = wave_scan_incl(incB);   // (wave-uniform)
         if (lane == 63) red[wave] = incA;
         __syncthreads();   // (also: the zero fill is done)
         uint32_t base = 0, tot = 0;
@@ -1038,6 +1084,75 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
     return r;
 }
 
+// The exit state alone, as fast as it can be had: K1's first decode (from a guessed state) and the re-decodes of its rounds,
+// whose chains -- one lane after the other -- are what the kernel's duration is made of.  While the sub-sequence's end is
+// more than a first symbol (< LUT_BITS bits) away, AC symbols go two per step where the table has them (EntropyTables::
+// lutx: below k = 48 only, the single-symbol tables take over from there); the last symbols go one by one, so that the run
+// stops at the FIRST symbol boundary at or past `pend`, like every other decode of the same sub-sequence.
+__device__ __forceinline__ uint64_t run_exit(const LdsTables& T, const uint32_t* lutx, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend,
+                                             bool gray
+#if KPEG_SYNC_STATS
+                                             , uint32_t* iters_out
+#endif
+)
+{
+    const uint32_t tb_wrap = gray ? 2 * LUT_BYTES : 6 * LUT_BYTES;
+    BitReader br;
+    br.init(bits, w0, s.p);
+    uint32_t p = s.p, k = s.k, q = s.q, tb = state_table(s);
+#if KPEG_SYNC_STATS
+    uint32_t iters = 0;
+#endif
+    const char* const base_s = reinterpret_cast<const char*>(&T.lut[0][0]);
+    const char* const base_x = reinterpret_cast<const char*>(lutx);
+    constexpr uint32_t GUARD = LUT_BITS - 1;   // a first symbol of a pair is at most this long
+    if (p + GUARD < pend) {
+        uint32_t e1 = *reinterpret_cast<const uint32_t*>((k >= 48 ? base_s : base_x) + tb + ((br.peek() >> (32 - LUT_BITS)) << 2));
+        do {
+            const uint32_t win = br.peek();
+            const uint32_t e = lut_finish(T, tb, win, e1);
+            const uint32_t kraw = k + ((e >> 16) & 127);
+            const bool adv = kraw >= 64;
+            k = adv ? ((e >> 14) & 1u) : kraw;
+            q = adv ? ((e >> 25) & 1u) : q;
+            tb += adv ? LUT_BYTES : 0u;
+            tb = tb == tb_wrap ? 0u : tb;
+            p += e & 31;
+            br.consume(e & 31);
+            e1 = *reinterpret_cast<const uint32_t*>((k >= 48 ? base_s : base_x) + tb + ((br.peek() >> (32 - LUT_BITS)) << 2));
+#if KPEG_SYNC_STATS
+            iters++;
+#endif
+        } while (p + GUARD < pend);
+    }
+    uint32_t e1 = lut_first(T, tb, br.peek());
+    while (p < pend) {
+        const uint32_t win = br.peek();
+        const uint32_t e = lut_finish(T, tb, win, e1);
+        const uint32_t kraw = k + ((e >> 16) & 127);
+        const bool adv = kraw >= 64;
+        k = adv ? ((e >> 14) & 1u) : kraw;
+        q = adv ? ((e >> 25) & 1u) : q;
+        tb += adv ? LUT_BYTES : 0u;
+        tb = tb == tb_wrap ? 0u : tb;
+        p += e & 31;
+        br.consume(e & 31);
+        e1 = lut_first(T, tb, br.peek());
+#if KPEG_SYNC_STATS
+        iters++;
+#endif
+    }
+#if KPEG_SYNC_STATS
+    *iters_out = iters;
+#endif
+    DecState x;
+    x.p = p;
+    x.c = tb / (2 * LUT_BYTES);
+    x.k = k;
+    x.q = q;
+    return pack_state(x);
+}
+
 __device__ __forceinline__ uint32_t locate_segment(const uint32_t* __restrict__ sub_base, uint32_t nseg, uint32_t i)
 {
     // largest r with sub_base[r] <= i
@@ -1159,16 +1274,8 @@ __device__ void wsum_scan(int4* wsum, uint32_t* wrec, EntropyMeta* meta, uint32_
             if (COUNT) vr = __hip_atomic_load(&wrec[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // inclusive scan inside the wavefront by shuffles, the wavefronts' totals through LDS
-        int4 inc = v;
-        uint32_t incr = vr;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int x = __shfl_up(inc.x, o), y = __shfl_up(inc.y, o), z = __shfl_up(inc.z, o), w = __shfl_up(inc.w, o);
-            const uint32_t r = COUNT ? (uint32_t)__shfl_up((int)incr, o) : 0u;
-            if ((int)lane >= o) {
-                inc = make_int4(inc.x + x, inc.y + y, inc.z + z, inc.w + w);
-                incr += r;
-            }
-        }
+        const int4 inc = make_int4(wave_scan_incl(v.x), wave_scan_incl(v.y), wave_scan_incl(v.z), wave_scan_incl(v.w));
+        const uint32_t incr = COUNT ? wave_scan_incl(vr) : 0u;
         __syncthreads();   // (the totals of the chunk before have been read)
         if (lane == 63) {
             s[wave] = inc;
@@ -1227,7 +1334,8 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
 {
     KPEG_GEOMETRY(S);
     __shared__ __attribute__((aligned(16))) LdsTables T;
-    __shared__ int4 s_cnt[SYNC_WG];          // wsum_scan's scratch
+    __shared__ int4 s_cnt[2 * (SYNC_WG / 64)];   // wsum_scan's scratch
+    __shared__ __attribute__((aligned(16))) uint32_t s_lutx[S420 ? 4 : 6 * (1 << LUT_BITS)];   // run_exit's tables
     __shared__ uint64_t s_wexit[SYNC_WG / 64];   // every wavefront's last exit state so far ...
     __shared__ uint32_t s_wdone[SYNC_WG / 64];   // ... and whether it is final
     __shared__ uint64_t s_edge[2];           // entry state of the first own item, exit state of the last
@@ -1317,6 +1425,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     StuffedStage<S> stg;
     if (stuffed) stg.begin(a.scan, a.scan_len, ibase, nit + StuffedGeom<S>::EXTRA);   // (its loads fly while the tables load)
     load_tables(&T, a.tabs);
+    if (!S420) load_tables_x(s_lutx, a.tabs);
     // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
     uint32_t w0 = 0;
     if (stuffed) {
@@ -1341,6 +1450,23 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         return (x & 0xFFFFFFFF00000000ull) | (uint64_t)(((ibase + tl + 1) << VSHIFT) | (pl - s_start[tl + 1]));
     };
 
+    uint32_t ex_iters = 0;   // (stats builds: the steps of the last exit_of)
+    auto exit_of = [&](DecState d, uint32_t pe) __attribute__((always_inline)) -> uint64_t {
+        if (S420) {
+            const RunResult rx = run_count<COUNT, false, S420>(T, s_bits, w0, d, pe, a.gray != 0);
+#if KPEG_SYNC_STATS
+            ex_iters = rx.iters;
+#endif
+            return rx.exit_state;
+        }
+#if KPEG_SYNC_STATS
+        return run_exit(T, s_lutx, s_bits, w0, d, pe, a.gray != 0, &ex_iters);
+#else
+        return run_exit(T, s_lutx, s_bits, w0, d, pe, a.gray != 0);
+#endif
+    };
+    (void)ex_iters;
+
     // Every wavefront settles its 64 consecutive items on its own: no barrier, no work list.  An item's entry state
     // is its left neighbour's exit state -- one lane over (DPP shift), for lane 0 the last exit state of the
     // wavefront before, handed over through LDS -- and an item decodes again whenever that differs from the state it
@@ -1353,6 +1479,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     bool segfirst = false;      // opens a restart segment: its entry state is known
     bool fixed = true;          // never decodes again (segfirst; item 0 of pass 0: nothing to check its guess against)
     uint64_t used = 0;          // the state this item last decoded from
+    bool dirty = false;         // decoded in this launch: its counts are to be made
     RunResult r;
     r.exit_state = 0;
     r.cnt = make_int4(0, 0, 0, 0);
@@ -1386,11 +1513,11 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
                 if (stuffed) sv.p = (ibase + t) << VSHIFT;
                 used = pack_state(sv);
             }
-            r = run_count<COUNT, false, S420>(T, s_bits, w0, s, pend, a.gray != 0);   // exit state only: see below
-            r.exit_state = to_virtual(r.exit_state, t);
+            r.exit_state = to_virtual(exit_of(s, pend), t);   // exit state only: see below
+            dirty = true;
 #if KPEG_SYNC_STATS
             st_runs++;
-            st_iters += r.iters;
+            st_iters += ex_iters;
 #endif
         } else {
             r.exit_state = a.X[i0 + t];
@@ -1401,7 +1528,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     if (p != 0) {
         // the states the loaded results were decoded from: the left neighbour's exit state (they converged in an earlier
         // pass); item 0's was this workgroup's assumption
-        const uint64_t left = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)r.exit_state, 1) | ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(r.exit_state >> 32), 1) << 32);
+        const uint64_t left = (uint64_t)wave_shr1((uint32_t)r.exit_state) | ((uint64_t)wave_shr1((uint32_t)(r.exit_state >> 32)) << 32);
         used = lane ? left : (t ? (have ? a.X[i0 + t - 1] : 0ull) : a.assumed[g]);
     }
     // every wavefront's last exit state so far, before anybody looks
@@ -1443,21 +1570,20 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const uint64_t tmc = __builtin_amdgcn_s_memtime();
     uint64_t tr[6] = {0, 0, 0, 0, 0, 0};
     uint32_t act[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t tmb = 0;   // the rounds are over, the counts' decode begins
 #endif
     if (wave * 64 < nit) {
         const uint32_t last_lane = min(63u, nit - 1 - wave * 64);
         SpinGuard guard(K1_SPIN_TICKS);
-        bool first = true;
         for (;;) {
             // the wavefront before: done flag first, then its last exit state (written in the opposite order)
             const uint32_t prev_done = wave ? __hip_atomic_load(&s_wdone[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 1u;
             const uint64_t prev_x = wave ? __hip_atomic_load(&s_wexit[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : entry;
-            const uint64_t left = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)r.exit_state, 1) | ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(r.exit_state >> 32), 1) << 32);
-            // (pass 0: the first decode above kept no counts, so everybody decodes once more -- nearly everybody would
-            // anyway, a guessed entry state is almost never the true one; an item with a known entry state from that)
+            const uint64_t left = (uint64_t)wave_shr1((uint32_t)r.exit_state) | ((uint64_t)wave_shr1((uint32_t)(r.exit_state >> 32)) << 32);
+            // (exit states only, here: what the rounds cost is the longest chain of re-decodes, one lane after the other, so
+            // the step of these decodes is kept as short as it can be; the counts come after the rounds, see below)
             const uint64_t in = fixed ? used : (lane ? left : prev_x);
-            const bool again = have && ((p == 0 && first) || in != used);
-            first = false;
+            const bool again = have && in != used;
             if (!__ballot(again)) {
                 if (prev_done) break;
                 if (guard.expired()) {   // (cannot happen: the wavefronts of a workgroup run together; bounded like every wait)
@@ -1471,12 +1597,12 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
                 continue;
             }
             if (again) {
-                r = run_count<COUNT, true, S420>(T, s_bits, w0, to_local(in, t), pend, a.gray != 0);
-                r.exit_state = to_virtual(r.exit_state, t);
+                r.exit_state = to_virtual(exit_of(to_local(in, t), pend), t);
                 used = in;
+                dirty = true;
 #if KPEG_SYNC_STATS
                 st_runs++;
-                st_iters += r.iters;
+                st_iters += ex_iters;
 #endif
             }
 #if KPEG_SYNC_STATS
@@ -1493,6 +1619,20 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         if (lane == last_lane) {
             __hip_atomic_store(&s_wexit[wave], r.exit_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&s_wdone[wave], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // The entry states stand: now the counts (blocks, DC sums, records), every item that decoded above once more, all
+        // lanes of the wavefront together -- one decode with the longer step instead of one per round.
+#if KPEG_SYNC_STATS
+        tmb = __builtin_amdgcn_s_memtime();
+#endif
+        if (dirty && t >= wu) {   // (not the warm-up items: theirs are their own workgroup's to make)
+            const uint64_t xs = r.exit_state;
+            r = run_count<COUNT, true, S420>(T, s_bits, w0, to_local(used, t), pend, a.gray != 0);
+            r.exit_state = xs;
+#if KPEG_SYNC_STATS
+            st_runs++;
+            st_iters += r.iters;
+#endif
         }
     }
 #if KPEG_SYNC_STATS
@@ -1517,6 +1657,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             o[7] = st_wait;
             o[8] = tmc;
             for (int q = 0; q < 6; ++q) o[9 + q] = tr[q] | ((unsigned long long)act[q] << 56);
+            o[15] = tmb;
         }
     }
 #endif
@@ -1535,14 +1676,9 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         if (t == nit - 1) s_edge[1] = r.exit_state;
     }
     // per-workgroup totals for the scan
-    for (int o = 32; o > 0; o >>= 1) {
-        tot.x += __shfl_down(tot.x, o);
-        tot.y += __shfl_down(tot.y, o);
-        tot.z += __shfl_down(tot.z, o);
-        tot.w += __shfl_down(tot.w, o);
-        trec += __shfl_down(trec, o);
-    }
-    if ((t & 63) == 0) {
+    tot = make_int4(wave_scan_incl(tot.x), wave_scan_incl(tot.y), wave_scan_incl(tot.z), wave_scan_incl(tot.w));
+    trec = COUNT ? wave_scan_incl(trec) : 0u;
+    if ((t & 63) == 63) {
         s_red[t >> 6] = tot;
         s_redn[t >> 6] = trec;
     }
@@ -1690,17 +1826,9 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     {
         const int4 v = cnt_i;
         const uint32_t vr = nrec_i;
-        int4 inc = v;
-        uint32_t incr = vr;
         const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int x = __shfl_up(inc.x, o), y = __shfl_up(inc.y, o), z = __shfl_up(inc.z, o), w = __shfl_up(inc.w, o);
-            const uint32_t r = COMPACT ? (uint32_t)__shfl_up((int)incr, o) : 0u;
-            if ((int)lane >= o) {
-                inc = make_int4(inc.x + x, inc.y + y, inc.z + z, inc.w + w);
-                incr += r;
-            }
-        }
+        const int4 inc = make_int4(wave_scan_incl(v.x), wave_scan_incl(v.y), wave_scan_incl(v.z), wave_scan_incl(v.w));
+        const uint32_t incr = COMPACT ? wave_scan_incl(vr) : 0u;
         if (lane == 63) {
             s_wred[wave] = inc;
             if (COMPACT) s_wredr[wave] = incr;

@@ -37,7 +37,8 @@ print("  start            ", pct((k1[:, 0] - t0).astype(float)))
 print("  tables+stage     ", pct((k1[:, 1] - k1[:, 0]).astype(float)))
 print("  first decode     ", pct((k1[:, 2] - k1[:, 1]).astype(float)))
 print("  clear            ", pct((k1[:, 8] - k1[:, 2]).astype(float)))
-print("  rounds + waits   ", pct((k1[:, 3] - k1[:, 8]).astype(float)))
+print("  rounds + waits   ", pct((k1[:, 15] - k1[:, 8]).astype(float)))
+print("  counts' decode   ", pct((k1[:, 3] - k1[:, 15]).astype(float)))
 M = np.uint64((1 << 56) - 1)
 prev = k1[:, 8]
 for q in range(6):
