@@ -1173,6 +1173,20 @@ extern "C" int kpeg_hip_debug_words(kpeg_hip_ctx* ctx, uint32_t* out, int n)
     return KPEG_HIP_OK;
 }
 
+// test hook, host only (no device needed): the first-level Huffman tables as the kernels get them -- lut[4][512] (one symbol
+// per entry, [class * 2 + id]) and lutx[2][512] (K1's two-symbol AC entries) -- for tests/test_tables.py, which checks every
+// two-symbol entry against two steps through the one-symbol table.  lut_bits receives LUT_BITS.
+extern "C" int kpeg_hip_debug_entropy_luts(const kpeg_frame* frame, uint32_t* lut, uint32_t* lutx, int* lut_bits)
+{
+    if (!frame || !lut || !lutx || !lut_bits) return KPEG_HIP_E_ARG;
+    static kpeg_dev::EntropyTables t;   // (43 KB: not on the stack)
+    if (kpeg_dev::build_entropy_tables(frame, &t) != 0) return KPEG_HIP_E_ARG;
+    std::memcpy(lut, t.lut, sizeof(t.lut));
+    std::memcpy(lutx, t.lutx, sizeof(t.lutx));
+    *lut_bits = kpeg_dev::LUT_BITS;
+    return KPEG_HIP_OK;
+}
+
 #if KPEG_SYNC_STATS
 // experiment builds only: per-wavefront timelines of K1 pass 0 (which = 0) and K2 (1), tools/sync_dbg.py
 extern "C" int kpeg_hip_debug_entropy_stamps(int which, unsigned long long* out, int n)

@@ -113,3 +113,56 @@ def test_colour_arithmetic_is_exact_over_its_whole_range():
     k = np.arange(-270, 271, dtype=np.float64)   # ceil(t)
     arg = (yo[:, None].astype(np.float64) - k[None, :]).astype(f32)
     assert np.array_equal(cvt(arg), np.clip(ry[:, None].astype(np.int64) + 128 - k[None, :].astype(np.int64), 0, 255))
+
+
+def _luts(data):
+    import ctypes
+    import libkpeg_amd
+    lib = libkpeg_amd.load_hip()
+    p = T.oracle_parse(data)
+    frame = T.make_frame(p)
+    bits = ctypes.c_int(0)
+    lut = np.zeros((4, 512), np.uint32)
+    lutx = np.zeros((2, 512), np.uint32)
+    lib.kpeg_hip_debug_entropy_luts.argtypes = [ctypes.c_void_p] * 4
+    assert lib.kpeg_hip_debug_entropy_luts(ctypes.byref(frame), lut.ctypes.data, lutx.ctypes.data, ctypes.byref(bits)) == 0
+    assert bits.value == 9
+    return lut, lutx
+
+
+def test_two_symbol_entries_are_two_steps_through_the_one_symbol_table():
+    """K1's exit-state decodes take AC symbols two at a time from lutx (entropy.hip.h, run_exit) while k < 48.  Every such entry
+    must be what two steps through the one-symbol table give: bits used, coefficient advance, and -- wherever the first symbol
+    alone cannot end the block (k < 48) -- the same (k, table switch) afterwards, for every k.  Host code only: no GPU."""
+    E_LONG, E_BAD, E_ZERO, E_ACSYM = 1 << 31, 1 << 23, 1 << 15, 1 << 27
+    for data in (T.synth_jpeg(64, 64, seed=3), open(os.path.join(T.GOLDEN, "lena.jpg"), "rb").read()):
+        lut, lutx = _luts(data)
+        pairs = 0
+        for tid in range(2):
+            one = lut[2 + tid]
+            for j in range(512):
+                e1, x = int(one[j]), int(lutx[tid][j])
+                if x == e1:
+                    continue
+                pairs += 1
+                # only an AC symbol that is neither long, nor missing, nor EOB opens a pair
+                assert not (e1 & (E_LONG | E_BAD | E_ZERO)) and (e1 & E_ACSYM)
+                len1 = e1 & 31
+                e2 = int(one[(j << len1) & 511])
+                assert not (e2 & (E_LONG | E_BAD))
+                assert len1 + ((e2 >> 5) & 31) <= 9          # the second code lies inside the window: the entry is the same for all its copies
+                assert (x & 31) == len1 + (e2 & 31) <= 31
+                adv1, adv2 = (e1 >> 16) & 127, (e2 >> 16) & 127
+                assert 1 <= adv1 <= 16
+                assert (x >> 16) & 127 == adv1 + adv2
+                assert x & ~((127 << 16) | 31) == 0         # after the block: k = 0, q = 0; no other flag
+                for k in range(1, 48):
+                    # two steps, as run_count / K2 take them
+                    k1 = k + adv1
+                    assert k1 < 64
+                    k2 = k1 + adv2
+                    step2 = (0, True) if k2 >= 64 else (k2, False)
+                    kx = k + ((x >> 16) & 127)
+                    stepx = (0, True) if kx >= 64 else (kx, False)
+                    assert step2 == stepx
+        assert pairs > 100, pairs
