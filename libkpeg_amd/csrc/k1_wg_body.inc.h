@@ -27,15 +27,17 @@
     // stuffed mode: states that leave the workgroup carry virtual positions (chunk << VSHIFT | bit inside the chunk); the
     // decode loops run on positions in s_bits.  An item's entry state lies in its own chunk, its exit state in the next one.
     constexpr uint32_t VSHIFT = StuffedGeom<S>::VSHIFT;
+    // (this lane's item only: the bounds of its chunk are kept in registers -- pbeg, pend below -- not read again per round)
+    uint32_t pbeg = 0, pend = 0;
     auto to_local = [&](uint64_t v, uint32_t tl) -> DecState {
         DecState d = unpack_state(v);
-        if (stuffed) d.p = s_start[tl] + (d.p & ((1u << VSHIFT) - 1u));
+        if (stuffed) d.p = pbeg + (d.p & ((1u << VSHIFT) - 1u));
         return d;
     };
     auto to_virtual = [&](uint64_t x, uint32_t tl) -> uint64_t {
         if (!stuffed) return x;
         const uint32_t pl = (uint32_t)x;
-        return (x & 0xFFFFFFFF00000000ull) | (uint64_t)(((ibase + tl + 1) << VSHIFT) | (pl - s_start[tl + 1]));
+        return (x & 0xFFFFFFFF00000000ull) | (uint64_t)(((ibase + tl + 1) << VSHIFT) | (pl - pend));
     };
 
     uint32_t ex_iters = 0;   // (stats builds: the steps of the last exit_of)
@@ -63,7 +65,6 @@
     // another decode.
     const uint32_t lane = t & 63, wave = t >> 6;
     const bool have = t < nit;
-    uint32_t pend = 0;
     bool segfirst = false;      // opens a restart segment: its entry state is known
     bool fixed = true;          // never decodes again (segfirst; item 0 of pass 0: nothing to check its guess against)
     uint64_t used = 0;          // the state this item last decoded from
@@ -87,6 +88,7 @@
         } else {
             geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase + t);
         }
+        pbeg = geo.pstart;
         pend = geo.pend;
         segfirst = geo.li == 0;
         fixed = segfirst || (p == 0 && t == 0);
