@@ -1,4 +1,5 @@
 """On-device entropy decode (K0..K2) and the whole seam (scan bytes -> RGB) vs the oracle."""
+import os
 import sys
 
 import numpy as np
@@ -170,15 +171,11 @@ for (w, h, q, sigma, mode, warm) in [(1024, 512, 95, 0.0, 1, -1), (1024, 512, 95
     st, want = T.oracle_decode(data)
     p = T.oracle_parse(data)
     assert ctx.lib.kpeg_hip_debug_set(ctx._h, 2, warm) == 0
-    for launches in (3, 0):   # the verifying and the chained launch; k_sync_settle, which repairs wrong assumptions one by one
-        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 1, launches) == 0
-        got = ctx.decode_scan(T.make_frame(p), p.scan)
-        passes = int(ctx.timings()["sync_rounds"])
-        worst = max(worst, passes) if launches else worst
-        bad = np.argwhere(got != want)
-        assert bad.size == 0, (w, h, q, mode, warm, launches, passes, bad[:8].tolist(), len(bad))
-        if warm == 0 and launches == 0:
-            assert passes == 3, passes   # (without warm-up assumptions fail: k_sync_settle's repair loop ran)
+    got = ctx.decode_scan(T.make_frame(p), p.scan)
+    passes = int(ctx.timings()["sync_rounds"])
+    worst = max(worst, passes)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (w, h, q, mode, warm, passes, bad[:8].tolist(), len(bad))
 print("PASSES", worst)
 """
 
@@ -382,6 +379,28 @@ def test_full_size_8k_properties(ctx):
     st, want = T.oracle_decode(data, nthreads=16)
     assert st == T.DECODE_DONE
     assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("q,subseq", [(90, 0), (90, 96), (75, 96)])
+def test_photographic_content_whose_workgroups_guess_wrong(ctx, q, subseq):
+    """Synthetic fields never have a workgroup whose assumed entry state (from its warm-up) fails; photographs do -- smooth
+    regions repeat, and a decoder that is off by a component stays off until the content changes.  A golden photograph tiled
+    to 2560 x 1696 and re-encoded: K1's verifying launch has real work (tools/photo_k1.py: a few per cent of the
+    workgroups), with the bit rate's own sub-sequence size and with the sparse one forced."""
+    from PIL import Image
+    im = np.asarray(Image.open(os.path.join(T.GOLDEN, "nat_china_640x424_q90.jpg")).convert("RGB"))
+    big = np.ascontiguousarray(np.tile(im, (4, 4, 1)))
+    data = T.encode_rgb(big, quality=q)
+    st, want = T.oracle_decode(data)
+    assert st == T.DECODE_DONE
+    p = T.oracle_parse(data)
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, subseq) == 0
+    try:
+        got = ctx.decode_scan(T.make_frame(p), p.scan)
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 0)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, "first mismatches (y,x,c): %s of %d" % (bad[:8].tolist(), len(bad))
 
 
 @pytest.mark.parametrize("offset", [1, 7])
