@@ -70,7 +70,7 @@ namespace kpeg_dev {
 #endif
 // Bits per sub-sequence: a multiple of 32, >= 64.  K1/K2 exist for two sizes and the host picks per call from
 // the stream's bit rate: 96 (best on the 8K q75 workload, ~1 bit per pixel) and 384 for dense streams (from
-// 4 bits per pixel: they re-synchronise over thousands of bits, and fewer, longer rounds halve K1's time).
+// 3 bits per pixel: they re-synchronise over thousands of bits, and fewer, longer rounds halve K1's time).
 constexpr int SUBSEQ_SPARSE = KPEG_SUBSEQ_BITS, SUBSEQ_DENSE = KPEG_SUBSEQ_BITS_DENSE;
 constexpr int SYNC_WG = KPEG_SYNC_WG;          // threads per workgroup of K1 and K2
 constexpr int SYNC_PASSES = 3;   // sync kernels enqueued per call: pass 0, the verifying pass 1, the chained pass (+ scan of the totals)
@@ -2423,17 +2423,21 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
 #undef ENT_HIP
 }
 
-// Dense streams (from 4 bits per pixel) re-synchronise over thousands of bits: K1 then needs many rounds, and
+// Dense streams (from 3 bits per pixel) re-synchronise over thousands of bits: K1 then needs many rounds, and
 // four times longer sub-sequences mean a quarter of the rounds (each with its fixed cost) for the same
-// sequential chain; K2 pays ~40 % for them, K1 gains more (measured 1..19 bits per pixel).
+// sequential chain; K2 pays ~40-70 % for them, K1 gains more (measured 1..19 bits per pixel; the
+// switch-over by K1 + K2 on synthetic fields and on tiled photographs, 4K and 8K: tools/subseq_choice.py).
 static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, const EntropyLaunch& L, hipEvent_t* ev, bool* ev_rec,
                                  std::string* err)
 {
     const uint64_t bytes = L.nimg ? L.total_len : (uint64_t)L.scan_len;
-    // from 4 bits per pixel; 4:2:0 always: four luma blocks in a row share their tables, a decoder that is one block off
+    // from 3 to 4 bits per pixel; 4:2:0 always: four luma blocks in a row share their tables, a decoder that is one block off
     // stays plausible until the chroma blocks come, and streams re-synchronise several times more slowly (12 Mpixel:
     // K1 1.13 ms with 384-bit sub-sequences, 1.54 ms with 96)
-    const bool dense = L.subseq ? L.subseq >= SUBSEQ_DENSE : (L.sub420 != 0 || bytes * 8 >= (uint64_t)L.nmcu * 64 * 4);
+    // (from 3 bits per pixel on pictures of 4 Mpixel and more, where somewhere a chain of rounds is long; from 4 on small ones:
+    // lena.jpg, 512 x 512 at 3.2 bits per pixel, takes 0.15 ms with the short sub-sequences and 0.19 ms with the long ones)
+    const uint64_t bits = bytes * 8, px = (uint64_t)L.nmcu * 64;
+    const bool dense = L.subseq ? L.subseq >= SUBSEQ_DENSE : (L.sub420 != 0 || bits >= px * 4 || (bits >= px * 3 && px >= (4u << 20)));
     return dense ? entropy_decode_launch_s<SUBSEQ_DENSE>(S, tabs, L, ev, ev_rec, err)
                  : entropy_decode_launch_s<SUBSEQ_SPARSE>(S, tabs, L, ev, ev_rec, err);
 }
