@@ -107,6 +107,8 @@ constexpr int POOL_SUBS = KPEG_POOL_SUBS;             // second-level tables sha
 //   [25] DC symbol other than 0x00: the block keeps its AC terms (quirk Q1)
 //   [26] AC symbol that carries a non-zero coefficient (category > 0): one record of the compact coefficient stream
 //   [27] AC symbol other than EOB (a run: with a coefficient, or ZRL): must not run past the end of its block
+//   [30:28] coefficient index after the table's turn: 1 behind a DC symbol, 0 behind a block (run_exit reads it; its
+//        two-symbol entries, EntropyTables::lutx, also have 2..7 there, and [24] set = the turn of TWO tables ends)
 //   [31] code longer than LUT_BITS: [15:0] = second-level table in the pool, E_SEARCH = none left
 constexpr uint32_t E_ISDC = 1u << 14, E_ZERO = 1u << 15, E_BAD = 1u << 23, E_DCRUN = 1u << 24, E_KEEP = 1u << 25, E_REC = 1u << 26, E_ACSYM = 1u << 27,
                    E_LONG = 1u << 31;
@@ -118,13 +120,13 @@ __host__ __device__ inline uint32_t make_entry(uint32_t len, uint32_t sym, bool 
     const uint32_t kadv = isdc ? 65u : (sym == 0 ? 64u : run + 1);
     return (len + cat) | (len << 5) | (cat << 10) | (isdc ? E_ISDC : 0u) | (sym == 0 ? E_ZERO : 0u) | (kadv << 16) |
            ((isdc && run) ? E_DCRUN : 0u) | ((isdc && sym != 0) ? E_KEEP : 0u) | ((!isdc && cat != 0) ? E_REC : 0u) |
-           ((!isdc && sym != 0) ? E_ACSYM : 0u);
+           ((!isdc && sym != 0) ? E_ACSYM : 0u) | (isdc ? 1u << 28 : 0u);
 }
 // no such code: keep moving by 16 bits (only a speculative decode or a corrupt stream gets here;
 // the reference would never leave its bit loop, Decoder.cpp:704-748)
 __host__ __device__ inline uint32_t bad_entry(bool isdc)
 {
-    return 16u | (16u << 5) | (isdc ? E_ISDC : 0u) | E_ZERO | ((isdc ? 65u : 64u) << 16) | E_BAD;
+    return 16u | (16u << 5) | (isdc ? E_ISDC : 0u) | E_ZERO | ((isdc ? 65u : 64u) << 16) | E_BAD | (isdc ? 1u << 28 : 0u);
 }
 
 struct EntropyTables {  // built on the host per frame, copied to the device when it changes
@@ -138,10 +140,13 @@ struct EntropyTables {  // built on the host per frame, copied to the device whe
     float2 zzm[2][64];               // K2's one read per coefficient: .x = mscale_zz, .y (bits) = natural position << 8 | outside the 2x2 corner << 31
     float q00[2];                    // Q[0][0] of both tables
     float pad16[2];                  // (the tables are copied to LDS in 16-byte pieces)
-    // K1's exit-state decodes only (run_exit): the AC tables again, [id], with TWO symbols per entry wherever the second
-    // symbol's code still lies inside the LUT_BITS window.  Same fields: bits used = both symbols', coefficient advance = the
-    // sum (an EOB's 64 included).  Only looked up while k < 48, where the first symbol (advance <= 16) cannot end the block.
-    uint32_t lutx[2][1 << LUT_BITS];
+    // K1's exit-state decodes only (run_exit): the four tables again, [class * 2 + id], with TWO symbols per entry wherever
+    // the second symbol's code still lies inside the LUT_BITS window.  Same fields as a one-symbol entry, read the same way:
+    // bits used = both symbols'; AC AC: coefficient advance = the sum (an EOB's 64 included), only looked up while k < 48,
+    // where the first symbol (advance <= 16) cannot end the block; DC AC: advance 65 (the DC table's turn ends), index
+    // after it 1 + the AC symbol's advance (<= 7), Q1 flag of the DC symbol; DC EOB: the same with index 0, no flag, and
+    // bit 24: the turn of two tables ends.  (Bit 24 is E_DCRUN in a one-symbol DC entry: never set in these tables.)
+    uint32_t lutx[4][1 << LUT_BITS];
 };
 
 static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
@@ -210,14 +215,24 @@ static int build_entropy_tables(const kpeg_frame* f, EntropyTables* t)
         }
     for (int id = 0; id < 2; ++id)
         for (int j = 0; j < (1 << LUT_BITS); ++j) {
-            const uint32_t e1 = t->lut[2 + id][j];
-            uint32_t x = e1;
-            const uint32_t len1 = e1 & 31;
-            if (!(e1 & (E_LONG | E_BAD | E_ZERO)) && (e1 & E_ACSYM) && len1 < (uint32_t)LUT_BITS) {
-                const uint32_t room = LUT_BITS - len1;
-                const uint32_t e2 = t->lut[2 + id][(j << len1) & ((1 << LUT_BITS) - 1)];
-                if (!(e2 & (E_LONG | E_BAD)) && ((e2 >> 5) & 31) <= room)
-                    x = (len1 + (e2 & 31)) | ((((e1 >> 16) & 127) + ((e2 >> 16) & 127)) << 16);
+            // the symbol behind the first one, if its code lies inside the window: always an entry of the AC table
+            auto second = [&](uint32_t len1, uint32_t* e2) -> bool {
+                if (len1 >= (uint32_t)LUT_BITS) return false;
+                *e2 = t->lut[2 + id][(j << len1) & ((1 << LUT_BITS) - 1)];
+                return !(*e2 & (E_LONG | E_BAD)) && ((*e2 >> 5) & 31) <= LUT_BITS - len1;
+            };
+            uint32_t e2 = 0;
+            const uint32_t a1 = t->lut[2 + id][j];
+            uint32_t x = a1;
+            if (!(a1 & (E_LONG | E_BAD | E_ZERO)) && (a1 & E_ACSYM) && second(a1 & 31, &e2))
+                x = ((a1 & 31) + (e2 & 31)) | ((((a1 >> 16) & 127) + ((e2 >> 16) & 127)) << 16);
+            t->lutx[2 + id][j] = x;
+            const uint32_t d1 = t->lut[id][j];
+            x = d1 & ~E_DCRUN;
+            if (!(d1 & (E_LONG | E_BAD | E_DCRUN)) && second(d1 & 31, &e2)) {
+                const uint32_t adv2 = (e2 >> 16) & 127, len = (d1 & 31) + (e2 & 31);
+                if (e2 & E_ZERO) x = len | (65u << 16) | E_ISDC | E_DCRUN;                                  // DC EOB
+                else if (adv2 <= 6) x = len | (65u << 16) | E_ISDC | (d1 & E_KEEP) | ((1u + adv2) << 28);   // DC AC
             }
             t->lutx[id][j] = x;
         }
@@ -762,14 +777,16 @@ __device__ __forceinline__ void load_tables(LdsTables* dst, const EntropyTables*
     uint4* d = reinterpret_cast<uint4*>(&dst->pool[0][0]);
     for (uint32_t i = threadIdx.x; i < nbytes / 16; i += blockDim.x) d[i] = s[i];
 }
-// K1: the six slots once more, the AC slots with the two-symbol entries (the DC slots as they are: one base for all lookups)
+// K1: the six slots once more, with the two-symbol entries.  DCPAIR = false (dense streams: a DC symbol there rarely has
+// the next code inside the window, and the step is two instructions shorter without): the DC slots as they are.
+template <bool DCPAIR>
 __device__ __forceinline__ void load_tables_x(uint32_t* dst, const EntropyTables* src)
 {
     constexpr uint32_t LUT_V4 = (1u << LUT_BITS) / 4;
     uint4* l = reinterpret_cast<uint4*>(dst);
     for (uint32_t i = threadIdx.x; i < 6 * LUT_V4; i += blockDim.x) {
         const uint32_t slot = i / LUT_V4;
-        const uint32_t* tab = (slot & 1) ? &src->lutx[slot >= 2 ? 1 : 0][0] : &src->lut[slot_table(slot)][0];
+        const uint32_t* tab = (DCPAIR || (slot & 1)) ? &src->lutx[slot_table(slot)][0] : &src->lut[slot_table(slot)][0];
         l[i] = reinterpret_cast<const uint4*>(tab)[i - slot * LUT_V4];
     }
 }
@@ -1087,9 +1104,10 @@ __device__ __forceinline__ RunResult run_count(const LdsTables& T, const uint32_
 
 // The exit state alone, as fast as it can be had: K1's first decode (from a guessed state) and the re-decodes of its rounds,
 // whose chains -- one lane after the other -- are what the kernel's duration is made of.  While the sub-sequence's end is
-// more than a first symbol (< LUT_BITS bits) away, AC symbols go two per step where the table has them (EntropyTables::
-// lutx: below k = 48 only, the single-symbol tables take over from there); the last symbols go one by one, so that the run
-// stops at the FIRST symbol boundary at or past `pend`, like every other decode of the same sub-sequence.
+// more than a first symbol (< LUT_BITS bits) away, symbols go two per step where the table has them (EntropyTables::lutx:
+// AC AC below k = 48 only, the single-symbol tables take over from there; DC AC; DC EOB); the last symbols go one by one, so
+// that the run stops at the FIRST symbol boundary at or past `pend`, like every other decode of the same sub-sequence.
+template <bool DCPAIR>
 __device__ __forceinline__ uint64_t run_exit(const LdsTables& T, const uint32_t* lutx, const uint32_t* bits, uint32_t w0, DecState s, uint32_t pend,
                                              bool gray
 #if KPEG_SYNC_STATS
@@ -1111,12 +1129,13 @@ __device__ __forceinline__ uint64_t run_exit(const LdsTables& T, const uint32_t*
         uint32_t e1 = *reinterpret_cast<const uint32_t*>((k >= 48 ? base_s : base_x) + tb + ((br.peek() >> (32 - LUT_BITS)) << 2));
         do {
             const uint32_t win = br.peek();
-            const uint32_t e = lut_finish(T, tb, win, e1);
+            uint32_t e = e1;
+            if (e & E_LONG) e = lut_finish(T, tb, win, e) & ~E_DCRUN;   // (a one-symbol entry: its bit 24 means something else)
             const uint32_t kraw = k + ((e >> 16) & 127);
             const bool adv = kraw >= 64;
-            k = adv ? ((e >> 14) & 1u) : kraw;
+            k = adv ? ((e >> 28) & 7u) : kraw;
             q = adv ? ((e >> 25) & 1u) : q;
-            tb += adv ? LUT_BYTES : 0u;
+            tb += adv ? (DCPAIR ? LUT_BYTES << ((e >> 24) & 1u) : LUT_BYTES) : 0u;   // (a DC symbol with the EOB behind it ends the turn of two tables)
             tb = tb == tb_wrap ? 0u : tb;
             p += e & 31;
             br.consume(e & 31);
@@ -1454,7 +1473,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     StuffedStage<S> stg;
     if (stuffed) stg.begin(a.scan, a.scan_len, ibase, nit + StuffedGeom<S>::EXTRA);   // (its loads fly while the tables load)
     load_tables(&T, a.tabs);
-    if (!S420) load_tables_x(s_lutx, a.tabs);
+    if (!S420) load_tables_x<(S < SUBSEQ_DENSE)>(s_lutx, a.tabs);
     // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
     uint32_t w0 = 0;
     if (stuffed) {
@@ -1491,9 +1510,9 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             return rx.exit_state;
         }
 #if KPEG_SYNC_STATS
-        return run_exit(T, s_lutx, s_bits, w0, d, pe, a.gray != 0, &ex_iters);
+        return run_exit<(S < SUBSEQ_DENSE)>(T, s_lutx, s_bits, w0, d, pe, a.gray != 0, &ex_iters);
 #else
-        return run_exit(T, s_lutx, s_bits, w0, d, pe, a.gray != 0);
+        return run_exit<(S < SUBSEQ_DENSE)>(T, s_lutx, s_bits, w0, d, pe, a.gray != 0);
 #endif
     };
     (void)ex_iters;

@@ -1174,7 +1174,7 @@ extern "C" int kpeg_hip_debug_words(kpeg_hip_ctx* ctx, uint32_t* out, int n)
 }
 
 // test hook, host only (no device needed): the first-level Huffman tables as the kernels get them -- lut[4][512] (one symbol
-// per entry, [class * 2 + id]) and lutx[2][512] (K1's two-symbol AC entries) -- for tests/test_tables.py, which checks every
+// per entry, [class * 2 + id]) and lutx[4][512] (K1's two-symbol entries, same order) -- for tests/test_tables.py, which checks every
 // two-symbol entry against two steps through the one-symbol table.  lut_bits receives LUT_BITS.
 extern "C" int kpeg_hip_debug_entropy_luts(const kpeg_frame* frame, uint32_t* lut, uint32_t* lutx, int* lut_bits)
 {

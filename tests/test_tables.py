@@ -123,7 +123,7 @@ def _luts(data):
     frame = T.make_frame(p)
     bits = ctypes.c_int(0)
     lut = np.zeros((4, 512), np.uint32)
-    lutx = np.zeros((2, 512), np.uint32)
+    lutx = np.zeros((4, 512), np.uint32)
     lib.kpeg_hip_debug_entropy_luts.argtypes = [ctypes.c_void_p] * 4
     assert lib.kpeg_hip_debug_entropy_luts(ctypes.byref(frame), lut.ctypes.data, lutx.ctypes.data, ctypes.byref(bits)) == 0
     assert bits.value == 9
@@ -131,38 +131,69 @@ def _luts(data):
 
 
 def test_two_symbol_entries_are_two_steps_through_the_one_symbol_table():
-    """K1's exit-state decodes take AC symbols two at a time from lutx (entropy.hip.h, run_exit) while k < 48.  Every such entry
-    must be what two steps through the one-symbol table give: bits used, coefficient advance, and -- wherever the first symbol
-    alone cannot end the block (k < 48) -- the same (k, table switch) afterwards, for every k.  Host code only: no GPU."""
-    E_LONG, E_BAD, E_ZERO, E_ACSYM = 1 << 31, 1 << 23, 1 << 15, 1 << 27
+    """K1's exit-state decodes take symbols two at a time from lutx (entropy.hip.h, run_exit): AC AC while k < 48, DC AC,
+    DC EOB.  Every such entry must be what two steps through the one-symbol tables give -- bits used, coefficient index,
+    Q1 flag and table afterwards -- for every k it can be looked up with.  Host code only: no GPU."""
+    E_LONG, E_BAD, E_ZERO, E_ACSYM, E_DCRUN, E_KEEP = 1 << 31, 1 << 23, 1 << 15, 1 << 27, 1 << 24, 1 << 25
+
+    def step(e, k, q, tb):
+        """one symbol step as run_count and K2 take it (entropy.hip.h): (k, q, table) afterwards"""
+        kraw = k + ((e >> 16) & 127)
+        if kraw >= 64:
+            return (e >> 14) & 1, (e >> 25) & 1, tb + 1
+        return kraw, q, tb
+
+    def xstep(x, k, q, tb):
+        """the same for an entry of lutx, as run_exit reads it"""
+        kraw = k + ((x >> 16) & 127)
+        if kraw >= 64:
+            return (x >> 28) & 7, (x >> 25) & 1, tb + (2 if x & E_DCRUN else 1)
+        return kraw, q, tb
+
     for data in (T.synth_jpeg(64, 64, seed=3), open(os.path.join(T.GOLDEN, "lena.jpg"), "rb").read()):
         lut, lutx = _luts(data)
-        pairs = 0
+        pairs = dcpairs = 0
         for tid in range(2):
-            one = lut[2 + tid]
+            dc1, ac1 = lut[tid], lut[2 + tid]
             for j in range(512):
-                e1, x = int(one[j]), int(lutx[tid][j])
-                if x == e1:
+                # AC AC
+                e1, x = int(ac1[j]), int(lutx[2 + tid][j])
+                if x != e1:
+                    pairs += 1
+                    # only an AC symbol that is neither long, nor missing, nor EOB opens a pair
+                    assert not (e1 & (E_LONG | E_BAD | E_ZERO)) and (e1 & E_ACSYM)
+                    len1 = e1 & 31
+                    e2 = int(ac1[(j << len1) & 511])
+                    assert not (e2 & (E_LONG | E_BAD))
+                    assert len1 + ((e2 >> 5) & 31) <= 9      # the second code lies inside the window: the entry is the same for all its copies
+                    assert (x & 31) == len1 + (e2 & 31) <= 31
+                    assert 1 <= (e1 >> 16) & 127 <= 16
+                    for k in range(1, 48):
+                        for q in (0, 1):
+                            k1, q1, t1 = step(e1, k, q, 1)
+                            assert t1 == 1               # (the first symbol cannot end the block below k = 48)
+                            assert step(e2, k1, q1, t1) == xstep(x, k, q, 1)
+                else:
+                    # a one-symbol entry read as run_exit reads it
+                    if not (e1 & E_LONG):
+                        for k in (1, 20, 47, 48, 63):
+                            assert step(e1, k, 1, 1) == xstep(x, k, 1, 1)
+                # DC AC, DC EOB (k = 0 at a DC table, always)
+                d1, x = int(dc1[j]), int(lutx[tid][j])
+                if d1 & E_LONG:
+                    assert x == d1
                     continue
-                pairs += 1
-                # only an AC symbol that is neither long, nor missing, nor EOB opens a pair
-                assert not (e1 & (E_LONG | E_BAD | E_ZERO)) and (e1 & E_ACSYM)
-                len1 = e1 & 31
-                e2 = int(one[(j << len1) & 511])
-                assert not (e2 & (E_LONG | E_BAD))
-                assert len1 + ((e2 >> 5) & 31) <= 9          # the second code lies inside the window: the entry is the same for all its copies
+                if x == d1 & ~E_DCRUN:
+                    assert step(d1, 0, 0, 0) == xstep(x, 0, 0, 0)
+                    continue
+                dcpairs += 1
+                assert not (d1 & (E_BAD | E_DCRUN))
+                len1 = d1 & 31
+                e2 = int(ac1[(j << len1) & 511])
+                assert not (e2 & (E_LONG | E_BAD)) and len1 + ((e2 >> 5) & 31) <= 9
                 assert (x & 31) == len1 + (e2 & 31) <= 31
-                adv1, adv2 = (e1 >> 16) & 127, (e2 >> 16) & 127
-                assert 1 <= adv1 <= 16
-                assert (x >> 16) & 127 == adv1 + adv2
-                assert x & ~((127 << 16) | 31) == 0         # after the block: k = 0, q = 0; no other flag
-                for k in range(1, 48):
-                    # two steps, as run_count / K2 take them
-                    k1 = k + adv1
-                    assert k1 < 64
-                    k2 = k1 + adv2
-                    step2 = (0, True) if k2 >= 64 else (k2, False)
-                    kx = k + ((x >> 16) & 127)
-                    stepx = (0, True) if kx >= 64 else (kx, False)
-                    assert step2 == stepx
-        assert pairs > 100, pairs
+                for q in (0, 1):
+                    k1, q1, t1 = step(d1, 0, q, 0)
+                    assert (k1, t1) == (1, 1) and q1 == (1 if d1 & E_KEEP else 0)
+                    assert step(e2, k1, q1, t1) == xstep(x, 0, q, 0)
+        assert pairs > 100 and dcpairs > 50, (pairs, dcpairs)
