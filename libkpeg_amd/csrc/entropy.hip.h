@@ -274,6 +274,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t ticket;   // workgroups that have finished the chained pass
     uint32_t k0_slot[64], k0_top;   // K0's two-level ticket (restart segments: the last workgroup to finish sets the segments up)
     uint32_t k1_order;   // K1's chained pass: logical workgroup index = the order in which workgroups start (K0 clears it)
+    uint32_t fused_fail; // == the call's number: k_sync_write could not finish the call (the three launches behind it do)
 };
 
 // Waits between workgroups never rest on the order in which the hardware dispatches blockIdx (HIP promises none):
@@ -287,6 +288,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
 //    KPEG_HIP_E_DEVICE instead of the queue hanging.
 constexpr unsigned long long K0_SPIN_TICKS = 50000ull;        // 0.5 ms (a predecessor's 8 KiB take microseconds), then the fallback
 constexpr unsigned long long K1_SPIN_TICKS = 2000000000ull;   // 20 s: a predecessor's wait includes the whole chain before it
+constexpr unsigned long long FUSED_SPIN_TICKS = 100000ull;    // 1 ms: k_sync_write's waits; then the launches behind it take over
 struct SpinGuard {
     unsigned long long t0 = 0, limit;
     uint32_t polls = 0;
@@ -317,6 +319,8 @@ struct EntropyScratch {
     void* d_cnt = nullptr;      size_t cnt_cap = 0;     // cnt[nsub] int4
     void* d_wsum = nullptr;     size_t wsum_cap = 0;
     void* d_nrec = nullptr;     size_t nrec_cap = 0;    // nrec[nsub], wrec[nwg]: record counts of the compact coefficient stream
+    void* d_flags = nullptr;    size_t flags_cap = 0;   // k_sync_write: pub[nwg][PUB_WORDS]; zero when (re)allocated
+    uint32_t gen = 0;           // ... and the number of its last call (never 0 in a flag)
     EntropyMeta* d_meta = nullptr;
     EntropyTables* d_tabs = nullptr;
     EntropyTables h_tabs_cached;
@@ -325,7 +329,7 @@ struct EntropyScratch {
 
 static void entropy_scratch_free(EntropyScratch* s)
 {
-    void* ps[] = {s->d_u, s->d_part, s->d_segoff, s->d_state, s->d_cnt, s->d_wsum, s->d_nrec, s->d_meta, s->d_tabs};
+    void* ps[] = {s->d_u, s->d_part, s->d_segoff, s->d_state, s->d_cnt, s->d_wsum, s->d_nrec, s->d_flags, s->d_meta, s->d_tabs};
     for (void* p : ps)
         if (p) (void)hipFree(p);
     *s = EntropyScratch();
@@ -355,6 +359,7 @@ struct EntropyLaunch {
     uint32_t gray = 0;                   // one-component stream (kpeg_frame::components == 1)
     uint32_t sub420 = 0;                 // 4:2:0 (extension, dense layout): nmcu counts 16x16 MCUs of six blocks
     uint32_t force_k0 = 0;               // test / experiment hook: run K0 even where K1 and K2 could un-stuff for themselves
+    uint32_t fused_slots = 0;            // workgroups of k_sync_write the device holds at once (0: that kernel is not used)
     // fused batch: nimg > 0 independent scans decoded as the restart segments of one virtual stream (each starts
     // from the known state, DC predictors reset): d_scan / scan_len are unused, restart_interval = MCUs per image
     uint32_t nimg = 0;
@@ -1252,8 +1257,13 @@ struct SyncArgs {
     const uint8_t* scan;   // non-null: no K0 ran -- the sub-sequences are chunks of the byte-stuffed scan (stage_unstuff), nsub = nsub_host
     uint32_t scan_len;
     uint32_t nsub_host;
+    // k_sync_write (K1's pass 0 and K2 in one kernel): the call's number (never 0; 0 = not that path), and two words per
+    // workgroup that take it: its presets are done / its totals and states are published
+    uint32_t gen;
+    unsigned long long* pub;   // [nwg_cap][PUB_WORDS]: value | call number << 32, relaxed atomics both ways
 };
 constexpr uint64_t X_NONE = ~0ull;
+constexpr uint32_t PUB_WORDS = 9;   // blocks, dc0, dc1, dc2, records, exit state lo / hi, assumed entry state lo / hi
 
 // Appends v to list[] for every lane that wants to; call with the whole wavefront converged.
 __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list, uint32_t* counter)
@@ -1389,6 +1399,21 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const uint32_t nsub = stuffed ? a.nsub_host : a.meta->nsub, nseg = stuffed ? 1u : a.meta->nseg, n_u = stuffed ? 0u : a.meta->n_u;
     // The last launch (chained) also scans the workgroup totals: at once by workgroup 0 if the pass
     // before it moved nothing (the usual case), else by the workgroup that finishes the ripple last.
+    if (a.gen && p >= 1) {
+        if (a.meta->fused_fail != a.gen) return;   // k_sync_write finished the call
+        if (p == 1 && g * OWN < nsub) {
+            // what pass 0 does behind its first decode, k_sync_write left undone: the presets (it has every entry written by the
+            // one workgroup that owns it, or not at all), and the exchange slots its workgroups may have used
+            const uint32_t nwg = (nsub + OWN - 1) / OWN;
+            const uint32_t tper = (a.ntiles + 1 + nwg - 1) / nwg;
+            const uint32_t t0 = min(a.ntiles + 1, g * tper), t1 = min(a.ntiles + 1, t0 + tper);
+            for (uint32_t q = t0 + t; q < t1; q += SYNC_WG) a.tile_start[q] = 0u;
+            const uint32_t eper = (a.nblocks + nwg - 1) / nwg;
+            const uint32_t e0 = min(a.nblocks, g * eper), e1 = min(a.nblocks, e0 + eper);
+            for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = 0x7F800000u;
+            if (t == 0) a.bslot[g] = 0ull;
+        }
+    }
     int4 pre_v = make_int4(0, 0, 0, 0);
     uint32_t pre_r = 0;
     if (a.chained && g == 0 && stuffed) wsum_load<COUNT>(a.wsum, a.wrec, t, (nsub + OWN - 1) / OWN, false, pre_v, pre_r);   // (on its way with the flag below: the usual case needs it)
@@ -1464,300 +1489,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             return;
         }
     }
-#if KPEG_SYNC_STATS
-    const uint64_t tm0 = __builtin_amdgcn_s_memtime();
-#endif
-    const uint32_t nown = min((uint32_t)OWN, nsub - i0);
-    const uint32_t wu = p == 0 ? min(a.warm, i0) : 0u;
-    const uint32_t ibase = i0 - wu, nit = wu + nown;
-    StuffedStage<S> stg;
-    if (stuffed) stg.begin(a.scan, a.scan_len, ibase, nit + StuffedGeom<S>::EXTRA);   // (its loads fly while the tables load)
-    load_tables(&T, a.tabs);
-    if (!S420) load_tables_x<(S < SUBSEQ_DENSE)>(s_lutx, a.tabs);
-    // stage this workgroup's slice of the bit string (its sub-sequences are contiguous in u)
-    uint32_t w0 = 0;
-    if (stuffed) {
-        stg.finish(s_bits, STAGE_CAP, s_start, s_redn, a.scan_len);
-    } else {
-        w0 = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase).pstart >> 5;
-        const uint32_t total_words = (n_u + 3) / 4 + 2;
-        stage_bits(s_bits, STAGE_CAP, a.u, w0, total_words > w0 ? total_words - w0 : 0u);
-    }
-    __syncthreads();
-    // stuffed mode: states that leave the workgroup carry virtual positions (chunk << VSHIFT | bit inside the chunk); the
-    // decode loops run on positions in s_bits.  An item's entry state lies in its own chunk, its exit state in the next one.
-    constexpr uint32_t VSHIFT = StuffedGeom<S>::VSHIFT;
-    // (this lane's item only: the bounds of its chunk are kept in registers -- pbeg, pend below -- not read again per round)
-    uint32_t pbeg = 0, pend = 0;
-    auto to_local = [&](uint64_t v, uint32_t tl) -> DecState {
-        DecState d = unpack_state(v);
-        if (stuffed) d.p = pbeg + (d.p & ((1u << VSHIFT) - 1u));
-        return d;
-    };
-    auto to_virtual = [&](uint64_t x, uint32_t tl) -> uint64_t {
-        if (!stuffed) return x;
-        const uint32_t pl = (uint32_t)x;
-        return (x & 0xFFFFFFFF00000000ull) | (uint64_t)(((ibase + tl + 1) << VSHIFT) | (pl - pend));
-    };
-
-    uint32_t ex_iters = 0;   // (stats builds: the steps of the last exit_of)
-    auto exit_of = [&](DecState d, uint32_t pe) __attribute__((always_inline)) -> uint64_t {
-        if (S420) {
-            const RunResult rx = run_count<COUNT, false, S420>(T, s_bits, w0, d, pe, a.gray != 0);
-#if KPEG_SYNC_STATS
-            ex_iters = rx.iters;
-#endif
-            return rx.exit_state;
-        }
-#if KPEG_SYNC_STATS
-        return run_exit<(S < SUBSEQ_DENSE)>(T, s_lutx, s_bits, w0, d, pe, a.gray != 0, &ex_iters);
-#else
-        return run_exit<(S < SUBSEQ_DENSE)>(T, s_lutx, s_bits, w0, d, pe, a.gray != 0);
-#endif
-    };
-    (void)ex_iters;
-
-    // Every wavefront settles its 64 consecutive items on its own: no barrier, no work list.  An item's entry state
-    // is its left neighbour's exit state -- one lane over (DPP shift), for lane 0 the last exit state of the
-    // wavefront before, handed over through LDS -- and an item decodes again whenever that differs from the state it
-    // last decoded from.  A round costs the longest decode among the lanes that take part, not the longest of the
-    // workgroup, and nothing else.  A wavefront is done when the one before it is done and none of its lanes wants
-    // another decode.
-    const uint32_t lane = t & 63, wave = t >> 6;
-    const bool have = t < nit;
-    bool segfirst = false;      // opens a restart segment: its entry state is known
-    bool fixed = true;          // never decodes again (segfirst; item 0 of pass 0: nothing to check its guess against)
-    uint64_t used = 0;          // the state this item last decoded from
-    bool dirty = false;         // decoded in this launch: its counts are to be made
-    RunResult r;
-    r.exit_state = 0;
-    r.cnt = make_int4(0, 0, 0, 0);
-    r.nrec = 0;
-#if KPEG_SYNC_STATS
-    uint32_t st_runs = 0, st_iters = 0, st_rounds = 0, st_wait = 0;
-    r.iters = 0;
-    const uint64_t tm1 = __builtin_amdgcn_s_memtime();
-#endif
-    if (have) {
-        SubGeom geo;
-        if (stuffed) {
-            geo.seg = 0;
-            geo.li = ibase + t;
-            geo.pstart = s_start[t];
-            geo.pend = s_start[t + 1];
-        } else {
-            geo = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, ibase + t);
-        }
-        pbeg = geo.pstart;
-        pend = geo.pend;
-        segfirst = geo.li == 0;
-        fixed = segfirst || (p == 0 && t == 0);
-        if (p == 0) {
-            DecState s;
-            s.p = geo.pstart;
-            s.c = 0;
-            s.k = 0;
-            s.q = 0;
-            {
-                DecState sv = s;
-                if (stuffed) sv.p = (ibase + t) << VSHIFT;
-                used = pack_state(sv);
-            }
-            r.exit_state = to_virtual(exit_of(s, pend), t);   // exit state only: see below
-            dirty = true;
-#if KPEG_SYNC_STATS
-            st_runs++;
-            st_iters += ex_iters;
-#endif
-        } else {
-            r.exit_state = a.X[i0 + t];
-            r.cnt = a.cnt[i0 + t];
-            if (COUNT) r.nrec = a.nrec[i0 + t];
-        }
-    }
-    if (p != 0) {
-        // the states the loaded results were decoded from: the left neighbour's exit state (they converged in an earlier
-        // pass); item 0's was this workgroup's assumption
-        const uint64_t left = (uint64_t)wave_shr1((uint32_t)r.exit_state) | ((uint64_t)wave_shr1((uint32_t)(r.exit_state >> 32)) << 32);
-        used = lane ? left : (t ? (have ? a.X[i0 + t - 1] : 0ull) : a.assumed[g]);
-    }
-    // every wavefront's last exit state so far, before anybody looks
-    if (wave * 64 < nit && lane == min(63u, nit - 1 - wave * 64)) {
-        s_wexit[wave] = r.exit_state;
-        s_wdone[wave] = 0u;
-    }
-#if KPEG_SYNC_STATS
-    const uint64_t tm2 = __builtin_amdgcn_s_memtime();
-#endif
-#ifndef KPEG_ABLATE_NOZERO
-    // pass 0 clears the coefficient buffer behind the rounds below, which only touch LDS
-    if (p == 0) {
-        const uint32_t nwg = (nsub + OWN - 1) / OWN;   // the workgroups that get here
-        if (a.tile_start) {
-            // compact coefficient stream: nothing to clear but the tiles' first-record table (a tile whose first block a
-            // corrupt stream never starts then reads as empty)
-            const uint32_t tper = (a.ntiles + 1 + nwg - 1) / nwg;
-            const uint32_t t0 = min(a.ntiles + 1, g * tper), t1 = min(a.ntiles + 1, t0 + tper);
-            for (uint32_t q = t0 + t; q < t1; q += SYNC_WG) a.tile_start[q] = 0u;
-        } else {
-            const uint64_t per = (a.coef_n16 + nwg - 1) / nwg;
-            const uint64_t b0 = (uint64_t)g * per, b1 = min(a.coef_n16, b0 + per);
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            for (uint64_t q = b0 + t; q < b1; q += SYNC_WG) a.coef16[q] = z;
-        }
-        const uint32_t eper = (a.nblocks + nwg - 1) / nwg;
-        const uint32_t e0 = min(a.nblocks, g * eper), e1 = min(a.nblocks, e0 + eper);
-        // (grayscale: the MCU's chroma blocks stay all zero -- bound -0.0 = exact and corner-only; only luma is decoded)
-        for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = (a.gray && q % 3u) ? 0x80000000u : 0x7F800000u;
-        if (t == 0) {
-            a.bslot[g] = 0ull;
-            a.done[g] = 0u;
-        }
-    }
-#endif
-    __syncthreads();
-#if KPEG_SYNC_STATS
-    const uint64_t tmc = __builtin_amdgcn_s_memtime();
-    uint64_t tr[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t act[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t tmb = 0;   // the rounds are over, the counts' decode begins
-#endif
-    if (wave * 64 < nit) {
-        const uint32_t last_lane = min(63u, nit - 1 - wave * 64);
-        SpinGuard guard(K1_SPIN_TICKS);
-        for (;;) {
-            // the wavefront before: done flag first, then its last exit state (written in the opposite order)
-            const uint32_t prev_done = wave ? __hip_atomic_load(&s_wdone[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 1u;
-            const uint64_t prev_x = wave ? __hip_atomic_load(&s_wexit[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : entry;
-            const uint64_t left = (uint64_t)wave_shr1((uint32_t)r.exit_state) | ((uint64_t)wave_shr1((uint32_t)(r.exit_state >> 32)) << 32);
-            // (exit states only, here: what the rounds cost is the longest chain of re-decodes, one lane after the other, so
-            // the step of these decodes is kept as short as it can be; the counts come after the rounds, see below)
-            const uint64_t in = fixed ? used : (lane ? left : prev_x);
-            const bool again = have && in != used;
-            if (!__ballot(again)) {
-                if (prev_done) break;
-                if (guard.expired()) {   // (cannot happen: the wavefronts of a workgroup run together; bounded like every wait)
-                    if (lane == 0) atomicOr(&a.status[1], KPEG_ERR_TIMEOUT);
-                    break;
-                }
-#if KPEG_SYNC_STATS
-                st_wait++;
-#endif
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            if (again) {
-                r.exit_state = to_virtual(exit_of(to_local(in, t), pend), t);
-                used = in;
-                dirty = true;
-#if KPEG_SYNC_STATS
-                st_runs++;
-                st_iters += ex_iters;
-#endif
-            }
-#if KPEG_SYNC_STATS
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                if ((int)st_rounds == q) {
-                    tr[q] = __builtin_amdgcn_s_memtime();
-                    act[q] = (uint32_t)__popcll(__ballot(again));
-                }
-            st_rounds++;
-#endif
-            if (lane == last_lane) __hip_atomic_store(&s_wexit[wave], r.exit_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (lane == last_lane) {
-            __hip_atomic_store(&s_wexit[wave], r.exit_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&s_wdone[wave], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        // The entry states stand: now the counts (blocks, DC sums, records), every item that decoded above once more, all
-        // lanes of the wavefront together -- one decode with the longer step instead of one per round.
-#if KPEG_SYNC_STATS
-        tmb = __builtin_amdgcn_s_memtime();
-#endif
-        if (dirty && t >= wu) {   // (not the warm-up items: theirs are their own workgroup's to make)
-            const uint64_t xs = r.exit_state;
-            r = run_count<COUNT, true, S420>(T, s_bits, w0, to_local(used, t), pend, a.gray != 0);
-            r.exit_state = xs;
-#if KPEG_SYNC_STATS
-            st_runs++;
-            st_iters += r.iters;
-#endif
-        }
-    }
-#if KPEG_SYNC_STATS
-    {
-        const uint64_t tm3 = __builtin_amdgcn_s_memtime();
-        uint32_t sr = st_runs, si = st_iters, mx = st_iters;
-        for (int o = 32; o > 0; o >>= 1) {
-            sr += (uint32_t)__shfl_xor((int)sr, o);
-            si += (uint32_t)__shfl_xor((int)si, o);
-            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-        }
-        const uint32_t wid = g * (SYNC_WG / 64) + wave;
-        if (lane == 0 && p == 0 && wid < 8192) {
-            unsigned long long* o = &g_ent_stamp[0][wid * 16];
-            o[0] = tm0;
-            o[1] = tm1;
-            o[2] = tm2;
-            o[3] = tm3;
-            o[4] = __builtin_amdgcn_s_memrealtime();
-            o[5] = ((unsigned long long)st_rounds << 32) | sr;
-            o[6] = ((unsigned long long)mx << 32) | si;
-            o[7] = st_wait;
-            o[8] = tmc;
-            for (int q = 0; q < 6; ++q) o[9 + q] = tr[q] | ((unsigned long long)act[q] << 56);
-            o[15] = tmb;
-        }
-    }
-#endif
-
-    int4 tot = make_int4(0, 0, 0, 0);
-    uint32_t trec = 0;
-    if (have && t >= wu) {
-        a.X[i0 + t - wu] = r.exit_state;
-        tot = r.cnt;
-        a.cnt[i0 + t - wu] = tot;
-        if (COUNT) {
-            trec = r.nrec;
-            a.nrec[i0 + t - wu] = trec;
-        }
-        if (t == wu) s_edge[0] = segfirst ? X_NONE : used;   // what this workgroup's first own item decoded from
-        if (t == nit - 1) s_edge[1] = r.exit_state;
-    }
-    // per-workgroup totals for the scan
-    tot = make_int4(wave_scan_incl(tot.x), wave_scan_incl(tot.y), wave_scan_incl(tot.z), wave_scan_incl(tot.w));
-    trec = COUNT ? wave_scan_incl(trec) : 0u;
-    if ((t & 63) == 63) {
-        s_red[t >> 6] = tot;
-        s_redn[t >> 6] = trec;
-    }
-    __syncthreads();
-    if (t == 0) {
-        int4 w = s_red[0];
-        uint32_t wr = s_redn[0];
-        for (int q = 1; q < SYNC_WG / 64; ++q) {
-            w = add4(w, s_red[q]);
-            wr += s_redn[q];
-        }
-        const uint64_t last = s_edge[1];
-        const bool known = s_edge[0] == X_NONE;   // first own sub-sequence opens a restart segment
-        a.wsum[g] = w;
-        a.wrec[g] = wr;
-        a.assumed[g] = s_edge[0];
-        Xb_cur[g] = last;
-        if (a.chained && !mute) {
-            __threadfence();
-            __hip_atomic_store(&a.done[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (p == 0) {
-            // nothing is verified before pass 1
-            if (!known) atomicAdd(&a.meta->moved[0], 1u);
-        } else if (!a.chained && last != Xb_prev[g] && i0 + nown < nsub) {
-            // the last workgroup has no successor: its movement needs no further pass
-            atomicAdd(&a.meta->moved[p], 1u);
-        }
-    }
+#include "k1_wg_body.inc.h"
     if (a.chained) {
         __syncthreads();
         finish_chained();
@@ -1798,6 +1530,7 @@ struct WriteArgs {
     uint32_t scan_len;
     uint32_t nsub_host;
     EntropyMeta* meta_reset; // the call's last entropy kernel leaves K1's bookkeeping zero for the next call
+    uint32_t gen;            // != 0: k_sync_write ran before this launch; nothing to do unless it gave up (meta->fused_fail == gen)
 };
 constexpr uint32_t TILE_BLOCKS = 24;   // K4's tile: 8 MCUs x 3 components
 
@@ -1836,6 +1569,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         a.meta_reset->ticket = 0;
         a.meta_reset->k1_order = 0;
     }
+    if (a.gen && a.meta->fused_fail != a.gen) return;   // k_sync_write finished the call
     const uint32_t i0 = blockIdx.x * OWN;
     if (i0 >= nsub) return;
 #if KPEG_SYNC_STATS
@@ -1871,389 +1605,195 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     __syncthreads();
     const uint64_t tw1 = __builtin_amdgcn_s_memtime();
 #endif
-    // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup (inside the wavefronts by
-    // shuffles, their totals through LDS: one barrier instead of the twenty of a scan that lives in LDS) ...
-    {
-        const int4 v = cnt_i;
-        const uint32_t vr = nrec_i;
-        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int4 inc = make_int4(wave_scan_incl(v.x), wave_scan_incl(v.y), wave_scan_incl(v.z), wave_scan_incl(v.w));
-        const uint32_t incr = COMPACT ? wave_scan_incl(vr) : 0u;
-        if (lane == 63) {
-            s_wred[wave] = inc;
-            if (COMPACT) s_wredr[wave] = incr;
-        }
-        __syncthreads();
-        int4 base = make_int4(0, 0, 0, 0);
-        uint32_t baser = 0;
-        for (uint32_t q = 0; q < SYNC_WG / 64; ++q)
-            if (q < wave) {
-                base = add4(base, s_wred[q]);
-                if (COMPACT) baser += s_wredr[q];
-            }
-        s_pre[threadIdx.x] = make_int4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
-        if (COMPACT) s_prer[threadIdx.x] = baser + incr - vr;   // exclusive
-        __syncthreads();   // (s_wred is used again below)
-    }
-    // ... + the workgroup's offset, counted from the start of the restart segment.  A segment that began in
-    // this workgroup re-bases on a neighbour's scan value; the one open at the workgroup's first
-    // sub-sequence began in an earlier workgroup: its base is that workgroup's offset + its cnt up to there.
-    int4 open_base = make_int4(0, 0, 0, 0);
-    if (nseg > 1 && g0.li != 0) {
-        const uint32_t first0 = a.sub_base[g0.seg], gf = first0 / OWN, lf = first0 - gf * OWN;
-        int4 part = make_int4(0, 0, 0, 0);
-        for (uint32_t j = threadIdx.x; j < lf; j += SYNC_WG) part = add4(part, a.cnt[gf * OWN + j]);
-        for (int o = 32; o > 0; o >>= 1) {
-            part.x += __shfl_down(part.x, o);
-            part.y += __shfl_down(part.y, o);
-            part.z += __shfl_down(part.z, o);
-            part.w += __shfl_down(part.w, o);
-        }
-        if ((threadIdx.x & 63) == 0) s_wred[threadIdx.x >> 6] = part;
-        __syncthreads();
-        open_base = a.wsum[gf];
-        for (int q = 0; q < SYNC_WG / 64; ++q) open_base = add4(open_base, s_wred[q]);
-    }
-    __syncthreads();
+#define K2_S_START s_start
+#include "k2_core.inc.h"
+#undef K2_S_START
+}
 
-#if KPEG_SYNC_STATS
-    const uint64_t tw2 = __builtin_amdgcn_s_memtime();
-#endif
-    uint32_t err = 0;
-    // the block open at this lane's entry, if it ends here: this lane's share of its bound
-    bool head = false;
-    float hA = 0.0f;
-    int hnnz = 0;
-    bool hcorner = true;
-    uint32_t hgb = 0;
-    int hchroma = 0;
-    // this lane's share of the block open at its exit: (A, nnz, flags)
-    int4 share = make_int4(0, 0, 0, 0);
-    uint32_t tail_gb = 0;
-    int tail_chroma = 0;
-    constexpr int SH_OPEN = 1, SH_CORNER = 2, SH_STARTED = 4;
-    int4 pre = make_int4(0, 0, 0, 0);
-    SubGeom g;
-    g.seg = g.li = g.pstart = g.pend = 0;
-    DecState s;
-    s.p = s.c = s.k = s.q = 0;
-    uint32_t first = 0;
-    if (valid) {
-        if (stuffed) {
-            g.seg = 0;
-            g.li = i;
-            g.pstart = s_start[threadIdx.x];
-            g.pend = s_start[threadIdx.x + 1];
-        } else {
-            g = sub_geom<S>(a.seg_off, a.sub_base, nseg, n_u, i);
-        }
-        if (g.li == 0) {
-            s.p = g.pstart;
-            s.c = 0;
-            s.k = 0;
-            s.q = 0;
-        } else {
-            s = unpack_state(x_prev);
-            if (stuffed) s.p = g.pstart + (s.p & ((1u << StuffedGeom<S>::VSHIFT) - 1u));   // virtual position: it lies in this lane's chunk
-        }
-        // block index and DC predictors at entry, relative to the segment start
-        first = stuffed ? 0u : a.sub_base[g.seg];
-        if (g.li != 0) {
-            const int4 loc = s_pre[threadIdx.x];
-            if (nseg == 1) {
-                pre = add4(wsum_g, loc);
-            } else if (first >= i0) {
-                const int4 f = s_pre[first - i0];
-                pre = make_int4(loc.x - f.x, loc.y - f.y, loc.z - f.z, loc.w - f.w);
-            } else {
-                const int4 w = wsum_g;
-                pre = make_int4(w.x + loc.x - open_base.x, w.y + loc.y - open_base.y, w.z + loc.z - open_base.z, w.w + loc.w - open_base.w);
-            }
-        }
-    }
-    // Everybody has read the scan's values: until the shares go there after the loop, a lane's s_pre slot is its ring of four
-    // records (compact stream) -- records leave as one aligned 16-byte store per four instead of four 4-byte stores, a quarter
-    // of the store instructions and of the cache-line requests behind them.
-    __syncthreads();
-    if (valid) {
-        const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
-        const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
-        const bool gray = !COMPACT && !S420 && a.gray != 0;     // one block per MCU, stored as the MCU's luma block (stride 3); dense layout only
-        const uint32_t bstride = gray ? 3u : 1u;
-        constexpr uint32_t BPM = S420 ? 6u : 3u;       // blocks per MCU (4:2:0, extension: Y Y Y Y Cb Cr)
-        const uint32_t blk_limit = gray ? seg_mcus : seg_mcus * BPM;   // blocks of this segment
-        uint32_t b = (uint32_t)pre.x;                  // blocks started so far, within the segment
-
-        BitReader br;
-        br.init(s_bits, w0, s.p);
-        uint32_t p = s.p, k = s.k, tb = state_table(s);
-        const uint32_t tb_wrap = S420 ? 12 * LUT_BYTES : (gray ? 2 * LUT_BYTES : 6 * LUT_BYTES);
-        // DC predictors rotate with the blocks (4:2:0: one per component, pd0 = Y, pd1 = Cb, pd2 = Cr): pd0 belongs to the next block to start (component b % 3,
-        // == the component of the table in use on a valid stream); DCDiff[c] += zz[0] (MCU.cpp:107)
-        const uint32_t cb = (gray || S420) ? 0u : b % 3;
-        int pd0 = cb == 0 ? pre.y : (cb == 1 ? pre.z : pre.w);
-        int pd1 = cb == 0 ? pre.z : (cb == 1 ? pre.w : pre.y);
-        int pd2 = cb == 0 ? pre.w : (cb == 1 ? pre.y : pre.z);
-        // State of the block in progress.  A lane that enters inside a block carries that block as its HEAD: the first
-        // block end it meets closes a block somebody else began (its bound is settled after the loop, from the shares);
-        // every later block began here with its DC symbol.
-        // (flags as bits of one register: booleans carried round the loop would live in SGPR masks that the compiler
-        // re-merges every iteration, a dozen scalar instructions each time)
-        constexpr uint32_t FL_INHEAD = 1;    // the block in progress began in an earlier lane
-        constexpr uint32_t FL_HADHEAD = 2;   // ... and ended here
-        constexpr uint32_t FL_HNC = 4;       // ... with a term outside the 2x2 corner
-        constexpr uint32_t FL_LAST = 8;      // the segment's last block ended here
-        uint32_t fl = s.k != 0 ? FL_INHEAD : 0u;
-        uint32_t keep = s.q ? E_REC : 0u;    // E_REC while the block keeps its AC terms: quirk Q1, a DC "EOB" drops them (MCU.cpp:97-100)
-        uint32_t ncw = 0;                    // bit 31: a non-zero AC term outside the 2x2 corner (natural 1, 8, 9 = zig-zag 1, 2, 4)
-        uint32_t ebits = 0;                  // E_BAD / E_DCRUN of every entry met
-        uint32_t over = 0;                   // entries whose run went past the end of a block (E_ACSYM of them)
-        uint32_t dcrange = 0;
-        // compact stream: where this lane's records go (K1 counted them: the scan gives every lane its first ordinal), and
-        // which block of which K4 tile the next block to start is (global block gbase + b = 24 tile + bmn)
-        uint32_t ord = 0, ord_end = 0, bmn = 0, tn = 0, bm_cur = 0;
-        uint32_t nq = 0;                     // records in the ring
-        uint32_t* const ring = reinterpret_cast<uint32_t*>(&s_pre[threadIdx.x]);
-        if (COMPACT) {
-            ord = wrec_g + s_prer[threadIdx.x];
-            ord_end = min(ord + nrec_i, a.rec_cap);
-            const uint32_t gbn = seg_mcu0 * 3 + b;
-            tn = gbn / TILE_BLOCKS;
-            bmn = gbn - tn * TILE_BLOCKS;
-            bm_cur = bmn ? bmn - 1 : TILE_BLOCKS - 1;   // the block in progress at entry (if any)
-        }
-        float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
-        int nnz = 0;
-        const uint32_t gbase = seg_mcu0 * BPM;
-        uint32_t gb = gbase + (b ? b - 1 : 0) * bstride;          // block in progress
-        constexpr uint32_t CHROMA_TB = S420 ? 8 * LUT_BYTES : 2 * LUT_BYTES;   // the first chroma table slot
-        uint32_t cur_chroma = tb >= CHROMA_TB ? 1u : 0u;          // ... and whether it is a chroma block
-        // What this lane may touch: a corrupt stream can count more blocks than the segment has.  No block beyond the
-        // segment's last is ever started (the loop ends with the block that completes the segment), so only the block in
-        // progress at entry can lie outside: such a lane does nothing.
-        uint32_t pend = g.pend;
-        if (k == 0 && b >= blk_limit) pend = 0;                   // the segment is complete
-        if (k != 0 && !(b >= 1 && b - 1 < blk_limit)) {
-            if (b == 0) err |= 64;                                // inside a block before the segment's first one began
-            pend = 0;                                             // (else: bits after the segment's last block, ignored as the reference ignores them)
-            fl = 0;
-        }
-        const float m00_l = T.zzm[0][0].x, m00_c = T.zzm[1][0].x;
-        uint32_t e1 = lut_first(T, phys_table<S420>(tb), br.peek());
-        while (p < pend) {
-            const uint32_t win = br.peek();
-            const uint32_t tbo = tb;
-            const uint32_t e = lut_finish(T, phys_table<S420>(tb), win, e1);
-#if KPEG_SYNC_STATS
-            st_steps++;
-#endif
-            p += e & 31;
-            br.consume(e & 31);
-            const uint32_t kraw = k + ((e >> 16) & 127);
-            const bool adv = kraw >= 64;
-            const bool isdc = (e & E_ISDC) != 0;
-            const bool chroma = tb >= CHROMA_TB;                  // the table in use: chroma tables
-            k = adv ? ((e >> 14) & 1u) : kraw;
-            tb += adv ? LUT_BYTES : 0u;
-            tb = tb == tb_wrap ? 0u : tb;
-            e1 = lut_first(T, phys_table<S420>(tb), br.peek());   // next symbol's entry on its way
-            const int ext = extend_win(win, (e >> 5) & 31, (e >> 10) & 15);
-            ebits |= e;
-            over |= kraw > 64 ? e : 0u;
-            if (isdc) {
-                // a DC symbol opens block gbase + b; its value is coefficient 0 (DC predictors: DCDiff[c] += zz[0], MCU.cpp:107)
-                int n;
-                if (S420) {
-                    n = (tbo < 8 * LUT_BYTES ? pd0 : (tbo == 8 * LUT_BYTES ? pd1 : pd2)) + ext;
-                    pd0 = tbo < 8 * LUT_BYTES ? n : pd0;
-                    pd1 = tbo == 8 * LUT_BYTES ? n : pd1;
-                    pd2 = tbo == 10 * LUT_BYTES ? n : pd2;
-                } else {
-                    n = pd0 + ext;
-                    pd0 = gray ? n : pd1;
-                    pd1 = gray ? pd1 : pd2;
-                    pd2 = gray ? pd2 : n;
-                }
-                dcrange |= (uint32_t)(n + 32768);   // bits above 15: the absolute DC does not fit the int16 coefficient layout
-                gb = gbase + b * bstride;
-                b++;
-                cur_chroma = chroma ? 1u : 0u;
-                keep = (e >> 25) & 1u ? E_REC : 0u; // E_KEEP
-                if (COMPACT) {
-                    bm_cur = bmn;
-                    if (bmn == 0 && tn <= a.ntiles) a.tile_start[tn] = ord;   // this tile's records begin here
-                    bmn++;
-                    if (bmn == TILE_BLOCKS) {
-                        bmn = 0;
-                        tn++;
-                    }
-                    a.dc16[gb] = (int16_t)n;
-                } else {
-                    a.coef[(size_t)gb << 6] = (int16_t)n;
-                }
-                // == the terms of block_ebound()'s A in idct_colour.hip.h (DC: 0.25 cc00 Q00, any rounding order is inside U's slack)
-                Asum = fabsf((float)n * (chroma ? m00_c : m00_l));
-                nnz = 0;
-                ncw = 0;
-            } else if ((e & keep) && kraw <= 64) {
-                // a non-zero AC coefficient (category > 0) at zig-zag position kraw - 1 of a block that keeps its AC terms:
-                // exactly what K1 counted as a record
-                const float2 zm = T.zzm[chroma ? 1 : 0][kraw - 1];   // scale, natural position << 8 | outside-the-corner << 31
-                const uint32_t zw = __float_as_uint(zm.y);
-                if (COMPACT) {
-                    if (ord < ord_end) {   // (always: K1 counted by the same rule)
-                        ring[nq] = ((uint32_t)ext << 16) | (zw & 0x3F00u) | bm_cur;
-                        nq++;
-                        ord++;
-                        if ((ord & 3u) == 0) {
-                            // a 16-byte boundary of the record array: the ring goes (whole: one store; a lane's first, shorter run: singly)
-                            const uint4 v = *reinterpret_cast<const uint4*>(ring);
-                            if (nq == 4) {
-                                *reinterpret_cast<uint4*>(a.rec + (ord - 4)) = v;
-                            } else {
-                                uint32_t* d = a.rec + (ord - nq);
-                                d[0] = v.x;
-                                if (nq > 1) d[1] = v.y;
-                                if (nq > 2) d[2] = v.z;
-                            }
-                            nq = 0;
-                        }
-                    }
-                } else {
-                    a.coef[((size_t)gb << 6) | ((zw >> 8) & 63u)] = (int16_t)ext;
-                }
-                Asum += fabsf((float)ext * zm.x);
-                nnz++;
-                ncw |= zw;
-            }
-            if (adv && !isdc) {
-                // the block is complete
-                if (b >= blk_limit) {
-                    pend = 0;                       // ... and with it the segment: nothing after it is this lane's (or anybody's)
-                    fl |= FL_LAST;
-                }
-                if (fl & FL_INHEAD) {
-                    fl = (fl & ~FL_INHEAD) | FL_HADHEAD | ((int)ncw < 0 ? FL_HNC : 0u);
-                    hA = Asum;
-                    hnnz = nnz;
-                    hgb = gb;
-                    hchroma = (int)cur_chroma;
-                } else {
-                    // == block_ebound() of idct_colour.hip.h (range guard: +inf sends the whole block to the exact path)
-                    const float E = nnz ? (0x1.004p-24f * Asum) * ((float)nnz + 14.5f) : 0.0f;
-                    // even mantissa, rounded up; lowest bit = chroma samples may leave the f32 colour range (Asum >= 249)
-                    const uint32_t Eb = ((__float_as_uint(E) + 1u) & ~1u) | ((cur_chroma && !(Asum < 249.0f)) ? 1u : 0u);
-                    const float Ef = __uint_as_float(Eb);
-                    a.ebound[gb] = !(Asum < 4000.0f) ? __builtin_inff() : ((int)ncw < 0 ? Ef : -Ef);
-                }
-                Asum = 0.0f;
-                nnz = 0;
-                ncw = 0;
-            }
-        }
-        if (COMPACT && nq) {   // what is left in the ring (fewer than four)
-            const uint4 v = *reinterpret_cast<const uint4*>(ring);
-            uint32_t* d = a.rec + (ord - nq);
-            d[0] = v.x;
-            if (nq > 1) d[1] = v.y;
-            if (nq > 2) d[2] = v.z;
-        }
-        if (ebits & E_BAD) err |= 8;
-        if (ebits & E_DCRUN) err |= 16;  // DC symbol with a run nibble: outside the contract
-        if (over & E_ACSYM) err |= 32;   // run past the end of a block
-        // the reference keeps its DC predictors as ints (MCU.cpp:107-112); one that leaves int16 would wrap here
-        // silently: outside the contract, reported instead
-        if (dcrange >> 16) err |= KPEG_ERR_DC_RANGE;
-        head = (fl & FL_HADHEAD) != 0;
-        hcorner = !(fl & FL_HNC);
-        tail_gb = gb;
-        tail_chroma = (int)cur_chroma;
-        if (k != 0 && pend != 0)   // (pend == 0: the lane did nothing, or the segment's last block ended here -- then k == 0)
-            share = make_int4(__float_as_int(Asum), nnz, SH_OPEN | ((int)ncw < 0 ? 0 : SH_CORNER) | ((fl & FL_INHEAD) ? 0 : SH_STARTED), 0);
-        // end of the last tile: by the lane in which the stream's last block ended (bits after it are ignored, as the
-        // reference ignores them: a later lane never gets here)
-        if (COMPACT && (fl & FL_LAST) && g.seg + 1 == nseg) a.tile_start[a.ntiles] = ord;
-        // the last sub-sequence of a segment must have produced the segment's last block, all of it
-        if (g.li + 1 == (stuffed ? nsub : a.sub_base[g.seg + 1] - first)) {
-            if (b < blk_limit) err |= 128;
-            if (k != 0 && b >= 1 && b - 1 < blk_limit) err |= 64;   // (bits after the segment's last block are ignored, as the reference ignores them)
-        }
-    }
-#if KPEG_SYNC_STATS
-    const uint64_t tw3 = __builtin_amdgcn_s_memtime();   // this wavefront's own decode loop is over
-#endif
-    __syncthreads();   // every lane has read its s_pre
-    s_pre[threadIdx.x] = share;
-    __syncthreads();
-    // (A, nnz, all-in-corner) of a split block as one 64-bit word for the exchange slots; never 0
-    auto pack = [](float A, int n, bool crn) -> unsigned long long {
-        return (unsigned long long)__float_as_uint(A) | ((unsigned long long)(uint32_t)n << 32) | ((unsigned long long)(crn ? 1u : 0u) << 40) |
-               (1ull << 63);
-    };
-    auto settle = [&](uint32_t blk, float A, int n, bool crn, int chroma) {
-        const float E = n ? (0x1.004p-24f * A) * ((float)n + 14.5f) : 0.0f;
-        const float Ef = __uint_as_float(((__float_as_uint(E) + 1u) & ~1u) | ((chroma && !(A < 249.0f)) ? 1u : 0u));
-        if (A < 4000.0f) a.ebound[blk] = crn ? -Ef : Ef;   // else the preset +inf stands
-    };
-    const uint32_t nown = min((uint32_t)OWN, nsub - i0);
-    const bool tail = threadIdx.x == nown - 1 && (share.z & SH_OPEN);   // the workgroup's last lane leaves a block open
-    for (int side = 0; side < 2; ++side) {
-        // side 0: the block open at entry that ended here; side 1: the block the workgroup's last lane leaves open
-        if (side == 0 ? !head : !tail) continue;
-        // add the shares of the lanes before this one, back to the lane where the block began
-        float A = side == 0 ? hA : __int_as_float(share.x);
-        int n = side == 0 ? hnnz : share.y;
-        bool crn = side == 0 ? hcorner : (share.z & SH_CORNER) != 0;
-        bool found = side == 1 && (share.z & SH_STARTED), broken = false;
-        for (int j = (int)threadIdx.x - 1; j >= 0 && !found && !broken; --j) {
-            const int4 sh = s_pre[j];
-            if (!(sh.z & SH_OPEN)) {
-                broken = true;   // inconsistent (corrupt stream): the preset +inf stands
-            } else {
-                A += __int_as_float(sh.x);
-                n += sh.y;
-                crn = crn && (sh.z & SH_CORNER);
-                found = (sh.z & SH_STARTED) != 0;
-            }
-        }
-        if (side == 0 && found) settle(hgb, A, n, crn, hchroma);
-        // the part of the block on this side of a workgroup boundary: swap it for the other side's
-        const bool to_prev = side == 0 && !found && !broken && blockIdx.x > 0;   // began before this workgroup
-        const bool to_next = side == 1 && found;                                  // goes on after this workgroup
-        if (to_prev || to_next) {
-            const unsigned long long other = atomicExch(&a.bslot[to_prev ? blockIdx.x - 1 : blockIdx.x], pack(A, n, crn));
-            if (other) {
-                // the sum runs in stream order on both sides: earlier part + later part
-                const float Ao = __uint_as_float((uint32_t)other);
-                const int no = (int)((other >> 32) & 0xFF);
-                const bool co = ((other >> 40) & 1) != 0;
-                settle(to_prev ? hgb : tail_gb, to_prev ? Ao + A : A + Ao, n + no, crn && co, to_prev ? hchroma : tail_chroma);
-            }
-        }
-    }
-    if (err) atomicOr(&a.status[1], err);
-#if KPEG_SYNC_STATS
+// K1's pass 0 and K2 in ONE kernel, for the case the headline is: one image without restart markers (no K0), the compact
+// coefficient stream, three components, sparse sub-sequences, and a grid that is resident all at once.  A workgroup does
+// K1's work on its sub-sequences (k1_wg_body.inc.h, as pass 0), publishes its totals, its last exit state and the entry
+// state it assumed, then waits until every workgroup before it has published, adds their totals up -- that is the scan --
+// and checks every assumption up to its own against the exit state it has to match.  If they all hold it writes its
+// coefficients straight away (k2_core.inc.h), from the tables and the bits it has in LDS already: no second prologue, no
+// verifying, chained or scan launch, and the workgroups in front of the image's slowest chain of re-decodes write while
+// that chain is still being walked.  If one does not hold (photographs: somewhere, always), or a wait expires, the
+// workgroup writes nothing and says so in meta->fused_fail: the verifying launch, the chained launch and k_write are
+// enqueued behind this kernel in any case and leave at once unless that word carries the call's number -- pass 0's results
+// are all in place for them.  Every wait is bounded (SpinGuard) and only ever for workgroups with a smaller index.
+template <int S>
+__global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sync_write(SyncArgs ka, WriteArgs a)
+{
+    KPEG_GEOMETRY(S);
+    constexpr bool COUNT = true, COMPACT = true, S420 = false;
+    __shared__ __attribute__((aligned(16))) LdsTables T;
+    __shared__ int4 s_cnt[2 * (SYNC_WG / 64)];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lutx[6 * (1 << LUT_BITS)];   // K1: run_exit's tables; K2: s_pre and s_prer
+    __shared__ uint64_t s_wexit[SYNC_WG / 64];
+    __shared__ uint32_t s_wdone[SYNC_WG / 64];
+    __shared__ uint64_t s_edge[2];
+    __shared__ uint32_t s_start[SYNC_WG + StuffedGeom<S>::EXTRA + 2];
+    __shared__ uint32_t s_n[1];
+    __shared__ int4 s_red[SYNC_WG / 64];
+    __shared__ uint32_t s_redn[SYNC_WG / 64];
+    constexpr uint32_t STAGE_CAP = ITEMS * SUBSEQ_WORDS + 1 + STAGE_MARGIN;
+    __shared__ uint32_t s_bits[STAGE_CAP];
+    static_assert(sizeof(s_lutx) >= SYNC_WG * (sizeof(int4) + sizeof(uint32_t)), "K2's scan arrays take the place of run_exit's tables");
+    (void)s_cnt;
+    const bool stuffed = true;   // (the host takes this path for such calls only)
+    const uint32_t nsub = ka.nsub_host, nseg = 1u, n_u = 0u;
+    const uint32_t i0 = blockIdx.x * OWN;
+    if (i0 >= nsub) return;
+    // ---- K1, pass 0 ----
+    uint64_t k1_exit = 0, k1_as = 0;
+    int4 k1_cnt = make_int4(0, 0, 0, 0);
+    uint32_t k1_nrec = 0, k1_wu = 0;
+    bool k1_own = false;
     {
-        const uint64_t tw4 = __builtin_amdgcn_s_memtime();
-        uint32_t mx = st_steps, sm = st_steps;
-        for (int o = 32; o > 0; o >>= 1) {
-            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-            sm += (uint32_t)__shfl_xor((int)sm, o);
-        }
-        const uint32_t wid = blockIdx.x * (SYNC_WG / 64) + (threadIdx.x >> 6);
-        if ((threadIdx.x & 63) == 0 && wid < 8192) {
-            unsigned long long* o = &g_ent_stamp[1][wid * 16];
-            o[0] = tw0;
-            o[1] = tw1;
-            o[2] = tw2;
-            o[3] = tw3;
-            o[4] = tw4;
-            o[5] = __builtin_amdgcn_s_memrealtime();
-            o[6] = ((unsigned long long)mx << 32) | sm;
-            o[7] = 0;
+        const SyncArgs& a = ka;
+        const int p = 0;
+        const uint32_t g = blockIdx.x, t = threadIdx.x;
+        uint64_t* const Xb_cur = a.Xb;
+        const uint64_t* const Xb_prev = a.Xb + a.nwg_cap;
+        const bool mute = false;
+        const uint64_t entry = 0;
+        (void)Xb_prev;
+#include "k1_wg_body.inc.h"
+        k1_exit = r.exit_state;
+        k1_cnt = r.cnt;
+        k1_nrec = r.nrec;
+        k1_wu = wu;
+        k1_own = have && t >= wu;
+        k1_as = s_edge[0];   // (what this workgroup's first own item decoded from: written before the body's last barrier)
+        // Published: every word carries its value and the call's number, stored and polled with relaxed atomics -- no
+        // fence anywhere (an agent-scope release writes this XCD's dirty L2 lines back, an acquire invalidates: per workgroup
+        // and per poll that doubled the kernel's time), no order between the words needed: each one says for itself
+        // whether it is there.
+        if (t == 0) {
+            const int4 w4 = a.wsum[g];         // (this thread's own stores above)
+            const uint32_t vals[PUB_WORDS] = {(uint32_t)w4.x, (uint32_t)w4.y, (uint32_t)w4.z, (uint32_t)w4.w, a.wrec[g],
+                                              (uint32_t)s_edge[1], (uint32_t)(s_edge[1] >> 32), (uint32_t)s_edge[0], (uint32_t)(s_edge[0] >> 32)};
+            for (uint32_t q = 0; q < PUB_WORDS; ++q)
+                __hip_atomic_store(&a.pub[(size_t)g * PUB_WORDS + q], (unsigned long long)vals[q] | ((unsigned long long)a.gen << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    const uint32_t gi = blockIdx.x, ti = threadIdx.x;
+    // ---- every workgroup before this one: wait, add up, check ----
+    int4 f_sum = make_int4(0, 0, 0, 0);
+    uint32_t f_rec = 0;
+    int f_bad = 0;
+    auto ldw = [&](uint32_t h, uint32_t q) -> unsigned long long {
+        return __hip_atomic_load(&ka.pub[(size_t)h * PUB_WORDS + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // Wavefront 0 waits for all of them, 64 first words per load, a chunk of 64 never looked at again once it was complete,
+    // two microseconds of sleep between looks: hundreds of workgroups wait here while others still decode on the same SIMDs.
+    if (ti < 64) {
+        const uint32_t nchunks = (gi + 63) / 64;
+        uint32_t rem = nchunks >= 32 ? 0xFFFFFFFFu : (1u << nchunks) - 1u;   // (<= 32 chunks: the grid is resident, < 2048 workgroups)
+        if (gi > 2048) f_bad = 2;
+        SpinGuard guard(FUSED_SPIN_TICKS);
+        while (rem && !f_bad) {
+            for (uint32_t c = 0; c < nchunks; ++c) {
+                if (!((rem >> c) & 1u)) continue;   // (wave-uniform)
+                const uint32_t h = c * 64 + ti;
+                const bool ok = h >= gi || (uint32_t)(ldw(h, 0) >> 32) == ka.gen;
+                if (__ballot(ok) == ~0ull) rem &= ~(1u << c);
+            }
+            if (rem) {
+                if (guard.expired()) f_bad = 2;
+                else __builtin_amdgcn_s_sleep(64);
+            }
+        }
+    }
+    if (__syncthreads_or(f_bad)) {
+        if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // every workgroup before this one has published (its first word is there; the others are on their way at worst): add
+    // their totals up, check every assumption up to this workgroup's own
+    auto word = [&](uint32_t h, uint32_t q, int& bad) -> uint32_t {
+        SpinGuard guard(FUSED_SPIN_TICKS);
+        unsigned long long v = ldw(h, q);
+        while ((uint32_t)(v >> 32) != ka.gen) {
+            if (guard.expired()) {
+                bad = 2;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            v = ldw(h, q);
+        }
+        return (uint32_t)v;
+    };
+    uint64_t x_before = 0;   // the exit state of the sub-sequence before this workgroup's first
+    for (uint32_t h = ti; h < gi; h += SYNC_WG) {
+        f_sum = add4(f_sum, make_int4((int)word(h, 0, f_bad), (int)word(h, 1, f_bad), (int)word(h, 2, f_bad), (int)word(h, 3, f_bad)));
+        f_rec += word(h, 4, f_bad);
+        const uint64_t xh = (uint64_t)word(h, 5, f_bad) | ((uint64_t)word(h, 6, f_bad) << 32);
+        // the workgroup behind h assumed something: this one's own assumption if that is this workgroup
+        const uint64_t as = h + 1 < gi ? ((uint64_t)word(h + 1, 7, f_bad) | ((uint64_t)word(h + 1, 8, f_bad) << 32)) : k1_as;
+        if (as != X_NONE && as != xh && !f_bad) f_bad = 1;
+        if (h + 1 == gi) x_before = xh;
+    }
+    // (x_before sits with the thread that handled workgroup gi - 1: through LDS below)
+    const bool has_before = gi > 0 && ((gi - 1) % SYNC_WG) == ti;
+    f_sum = make_int4(wave_scan_incl(f_sum.x), wave_scan_incl(f_sum.y), wave_scan_incl(f_sum.z), wave_scan_incl(f_sum.w));
+    f_rec = wave_scan_incl(f_rec);
+    __syncthreads();   // (K1's last readers of s_red / s_redn and of s_lutx are done)
+    if ((ti & 63) == 63) {
+        s_red[ti >> 6] = f_sum;
+        s_redn[ti >> 6] = f_rec;
+    }
+    if (has_before) s_wexit[0] = x_before;
+    const int f_anybad = __syncthreads_or(f_bad);
+    if (f_anybad) {
+        if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (gi == 0 && ti == 0) ka.status[2] = 1u;   // launches of K1 that had work (the launches behind this kernel say more if they run)
+    int4 wsum_g = make_int4(0, 0, 0, 0);
+    uint32_t wrec_g = 0;
+    for (uint32_t q = 0; q < SYNC_WG / 64; ++q) {
+        wsum_g = add4(wsum_g, s_red[q]);
+        wrec_g += s_redn[q];
+    }
+    x_before = s_wexit[0];
+    // ---- what K1's lanes know, handed to K2's lanes: item j of the workgroup sits on lane j + wu there, on lane j here ----
+    int4* const s_pre = reinterpret_cast<int4*>(s_lutx);
+    uint32_t* const s_prer = s_lutx + SYNC_WG * 4;
+    int4* const s_wred = s_red;
+    uint32_t* const s_wredr = s_redn;
+    uint64_t* const s_x = reinterpret_cast<uint64_t*>(s_lutx);
+    __syncthreads();   // (s_red, s_redn, s_wexit read)
+    if (k1_own) s_x[ti - k1_wu] = k1_exit;
+    __syncthreads();
+    const uint32_t i = i0 + ti;
+    const bool valid = ti < OWN && i < nsub;
+    const uint64_t x_prev = valid && i > 0 ? (ti > 0 ? s_x[ti - 1] : x_before) : 0ull;
+    __syncthreads();
+    if (k1_own) {
+        s_pre[ti - k1_wu] = k1_cnt;
+        s_prer[ti - k1_wu] = k1_nrec;
+    }
+    __syncthreads();
+    const int4 cnt_i = valid ? s_pre[ti] : make_int4(0, 0, 0, 0);
+    const uint32_t nrec_i = valid ? s_prer[ti] : 0u;
+    __syncthreads();
+    SubGeom g0;
+    g0.seg = 0;
+    g0.li = i0;
+    g0.pstart = 0;
+    g0.pend = 0;
+    const uint32_t w0 = 0;
+#if KPEG_SYNC_STATS
+    const uint64_t tw0 = __builtin_amdgcn_s_memtime();
+    uint32_t st_steps = 0;
+    const uint64_t tw1 = tw0;
 #endif
+    uint32_t* const k2_start = s_start + k1_wu;
+#define K2_S_START k2_start
+#include "k2_core.inc.h"
+#undef K2_S_START
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2389,20 +1929,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.scan = stuffed ? L.d_scan : nullptr;
     sa.scan_len = n;
     sa.nsub_host = nsub_host;
-    const int npass = L.sync_passes >= 3 ? L.sync_passes : SYNC_PASSES;   // the last one is chained and runs the scan
-    sa.part = (unsigned long long*)S->d_part;
-    sa.nparts = stuffed ? 0u : nparts;   // (K0's look-back words: untouched without K0)
-    for (int t = 0; t < npass; ++t) {
-        sa.pass = t;
-        sa.chained = t == npass - 1 ? 1 : 0;
-        if (L.sub420) hipLaunchKernelGGL((k_sync_pass<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
-        else if (L.d_tile_start) hipLaunchKernelGGL((k_sync_pass<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
-        else hipLaunchKernelGGL((k_sync_pass<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
-    }
-    mark(2);
-
-    mark(3);
-
+    sa.gen = 0;
+    sa.pub = nullptr;
     WriteArgs wa;
     wa.u = (const uint32_t*)S->d_u;
     wa.seg_off = seg_off;
@@ -2431,6 +1959,36 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     wa.scan_len = n;
     wa.nsub_host = nsub_host;
     wa.meta_reset = S->d_meta;
+    wa.gen = 0;
+    const int npass = L.sync_passes >= 3 ? L.sync_passes : SYNC_PASSES;   // the last one is chained and runs the scan
+    sa.part = (unsigned long long*)S->d_part;
+    sa.nparts = stuffed ? 0u : nparts;   // (K0's look-back words: untouched without K0)
+    // One kernel for K1's pass 0 and K2 (k_sync_write) where it applies; the launches below follow it in any case and leave
+    // at once unless it gave up.
+    bool fuse = false;
+    if constexpr (SB < SUBSEQ_DENSE) {
+        fuse = stuffed && L.d_tile_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= L.fused_slots;
+        if (fuse) {
+            void* const before = S->d_flags;
+            if ((rc = ent_grow(&S->d_flags, &S->flags_cap, (size_t)nwg_cap * PUB_WORDS * sizeof(unsigned long long), L.stream, err))) return rc;
+            if (S->d_flags != before) ENT_HIP(hipMemsetAsync(S->d_flags, 0, S->flags_cap, L.stream));
+            if (++S->gen == 0) ++S->gen;
+            sa.gen = wa.gen = S->gen;
+            sa.pub = (unsigned long long*)S->d_flags;
+            sa.pass = 0;
+            sa.chained = 0;
+            hipLaunchKernelGGL((k_sync_write<SB>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa, wa);
+        }
+    }
+    for (int t = fuse ? 1 : 0; t < npass; ++t) {
+        sa.pass = t;
+        sa.chained = t == npass - 1 ? 1 : 0;
+        if (L.sub420) hipLaunchKernelGGL((k_sync_pass<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        else if (L.d_tile_start) hipLaunchKernelGGL((k_sync_pass<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        else hipLaunchKernelGGL((k_sync_pass<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+    }
+    mark(2);
+    mark(3);
     if (L.sub420) hipLaunchKernelGGL((k_write<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else hipLaunchKernelGGL((k_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);

@@ -48,6 +48,8 @@ struct kpeg_hip_ctx {
     void* d_rgb = nullptr;
     size_t rgb_cap = 0;
     uint32_t force_k0 = 0;      // debug key 8 / KPEG_FORCE_K0
+    uint32_t fused_slots = 0;   // workgroups of k_sync_write resident at once; 0 = that kernel is not used (debug key 9 / KPEG_FUSED=0)
+    uint32_t fused_slots_dev = 0;   // ... as the device reports it
     void* d_pad = nullptr;      // any-size extension: the padded picture K4 writes before the crop
     size_t pad_cap = 0;
     void* d_ebound = nullptr;  // per-block error bounds for K4 (written by K2 or k_ebound)
@@ -191,6 +193,13 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
             if (v > 0) ctx->k4_wgs_per_cu = v;
         }
         if (const char* s = std::getenv("KPEG_FORCE_K0")) ctx->force_k0 = std::atoi(s) ? 1u : 0u;
+        {
+            int nf = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, kpeg_dev::k_sync_write<kpeg_dev::SUBSEQ_SPARSE>, kpeg_dev::SYNC_WG, 0) == hipSuccess && nf > 0)
+                ctx->fused_slots_dev = (uint32_t)nf * (uint32_t)ctx->num_cus;
+            ctx->fused_slots = ctx->fused_slots_dev;
+            if (const char* s = std::getenv("KPEG_FUSED")) ctx->fused_slots = std::atoi(s) ? ctx->fused_slots_dev : 0u;   // experiments: as debug key 9
+        }
         if (const char* s = std::getenv("KPEG_COEF_LAYOUT")) ctx->coef_layout = std::atoi(s);   // experiments: as kpeg_hip_debug_set key 7
         if (std::getenv("KPEG_DEBUG")) std::fprintf(stderr, "kpeg_hip: K4 workgroups per CU: %d (occupancy query %d), %d wavefronts each\n", ctx->k4_wgs_per_cu, nb, K4_WAVES);
     }
@@ -544,6 +553,7 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
     L.gray = f->components == 1 ? 1u : 0u;
     L.sub420 = sub420 ? 1u : 0u;
     L.force_k0 = ctx->force_k0;
+    L.fused_slots = ctx->fused_slots;
     if (compact) {
         // a record takes at least two bits of the stream (a one-bit code and a one-bit magnitude), a block holds at most 63
         const uint64_t bytes = batch ? batch->total_len : (uint64_t)scan_len;
@@ -804,6 +814,7 @@ static int ensure_lanes(kpeg_hip_ctx* ctx)
         ctx->lanes[l]->warm = ctx->warm;
         ctx->lanes[l]->subseq = ctx->subseq;
         ctx->lanes[l]->coef_layout = ctx->coef_layout;
+        ctx->lanes[l]->fused_slots = ctx->fused_slots ? ctx->lanes[l]->fused_slots_dev : 0u;
     }
     for (int l = 0; l <= kpeg_hip_ctx::NLANES; ++l)
         if (!ctx->lane_ev[l]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
@@ -1161,6 +1172,7 @@ extern "C" int kpeg_hip_debug_set(kpeg_hip_ctx* ctx, int key, int value)
     else if (key == 6) ctx->fault = (uint32_t)value;
     else if (key == 7) ctx->coef_layout = value;
     else if (key == 8) ctx->force_k0 = value ? 1u : 0u;   // K0 even for one image without restart markers (K1 and K2 un-stuff for themselves there)
+    else if (key == 9) ctx->fused_slots = value ? ctx->fused_slots_dev : 0u;   // k_sync_write (K1's pass 0 and K2 in one kernel) where it applies
     else return KPEG_HIP_E_ARG;
     return KPEG_HIP_OK;
 }

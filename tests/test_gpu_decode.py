@@ -403,6 +403,86 @@ def test_photographic_content_whose_workgroups_guess_wrong(ctx, q, subseq):
     assert bad.size == 0, "first mismatches (y,x,c): %s of %d" % (bad[:8].tolist(), len(bad))
 
 
+@pytest.mark.parametrize("case", ["synthetic", "photograph", "small", "dense", "corrupt", "unaligned"])
+def test_one_kernel_for_sync_and_write(ctx, case):
+    """k_sync_write (K1's pass 0 and K2 in one kernel; debug key 9) on the calls it takes -- one image, no restart markers,
+    compact stream, sparse sub-sequences -- and on those it must hand on: a photograph (some workgroup's assumed entry
+    state fails: the verifying launch and k_write behind it finish the call), a dense stream and a corrupt one."""
+    from PIL import Image
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 2) == 0     # the compact stream wherever it is possible
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1) == 0
+    try:
+        if case == "photograph":
+            im = np.asarray(Image.open(os.path.join(T.GOLDEN, "nat_china_640x424_q90.jpg")).convert("RGB"))
+            data = T.encode_rgb(np.ascontiguousarray(np.tile(im, (4, 4, 1))), quality=85)
+        elif case == "small":
+            data = T.synth_jpeg(64, 64, seed=5)
+        elif case == "dense":
+            data = T.synth_jpeg(1024, 512, seed=21, quality=95, sigma=0.0, mode=1)
+        else:
+            data = T.synth_jpeg(2560, 1440, seed=77, quality=75, sigma=6.0)
+        st, want = T.oracle_decode(data)
+        p = T.oracle_parse(data)
+        frame = T.make_frame(p)
+        if case == "corrupt":
+            import libkpeg_amd as K
+            rng = np.random.default_rng(5)
+            for _ in range(6):
+                bad = bytearray(p.scan)
+                for pos in rng.integers(0, len(bad), 4):
+                    bad[pos] ^= 1 << int(rng.integers(0, 8))
+                try:
+                    ctx.decode_scan(frame, bytes(bad))
+                except K.KpegError:
+                    pass
+            got = ctx.decode_scan(frame, p.scan)      # and the context is as good as new
+        elif case == "unaligned":
+            import torch
+            buf = torch.zeros(len(p.scan) + 16, dtype=torch.uint8, device="cuda")
+            buf[3:3 + len(p.scan)] = torch.frombuffer(bytearray(p.scan), dtype=torch.uint8).cuda()
+            out = torch.empty(want.shape, dtype=torch.uint8, device="cuda")
+            for _ in range(3):
+                ctx.decode_scan_dev(frame, buf.data_ptr() + 3, len(p.scan), out.data_ptr())
+            ctx.sync()
+            got = out.cpu().numpy()
+        else:
+            got = None
+            for _ in range(3):                         # (the call's number changes; the flags of the call before must not count)
+                got = ctx.decode_scan(frame, p.scan)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, "first mismatches (y,x,c): %s of %d" % (bad[:8].tolist(), len(bad))
+        # the same call through the separate launches (k_sync_write is the default where it applies)
+        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 0) == 0
+        got = ctx.decode_scan(frame, p.scan)
+        assert int(ctx.timings()["sync_rounds"]) >= 2
+        assert np.array_equal(got, want)
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+
+
+def test_one_kernel_for_sync_and_write_leaves_nothing_from_the_call_before(ctx):
+    """k_sync_write makes no presets (every first-record entry and error bound is written by the one workgroup that owns it):
+    two different pictures of one size, decoded in turns, must not see each other's."""
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 2) == 0
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1) == 0
+    try:
+        pics = []
+        for seed, q, sigma in ((11, 75, 6.0), (12, 50, 1.0), (13, 88, 9.0)):
+            data = T.synth_jpeg(1920, 1088, seed=seed, quality=q, sigma=sigma)
+            st, want = T.oracle_decode(data)
+            p = T.oracle_parse(data)
+            pics.append((T.make_frame(p), p.scan, want))
+        for turn in range(6):
+            frame, scan, want = pics[turn % 3]
+            got = ctx.decode_scan(frame, scan)
+            assert int(ctx.timings()["sync_rounds"]) == 1, "k_sync_write did not finish this call itself"
+            bad = np.argwhere(got != want)
+            assert bad.size == 0, (turn, bad[:8].tolist(), len(bad))
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+
+
 @pytest.mark.parametrize("offset", [1, 7])
 def test_unaligned_scan_pointer(ctx, offset):
     """The scan pointer has any alignment.  K0 (kept for restart segments and batches; forced here with debug key 8) loads
