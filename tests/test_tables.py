@@ -47,7 +47,7 @@ def test_kernel_error_constant_covers_the_derived_bound():
     kk = float(re.search(r"#define KPEG_KAPPA ([0-9.]+)f", src).group(1))
     assert 10.0 < k <= kk < k + 1.0, (k, kk)
     # K2 writes the same bound formula as block_ebound()
-    ent = open(os.path.join(CSRC, "entropy.hip.h")).read()
+    ent = open(os.path.join(CSRC, "entropy.hip.h")).read() + open(os.path.join(CSRC, "k2_core.inc.h")).read()
     assert "(0x1.004p-24f * Asum) * ((float)nnz + %sf)" % ("%.1f" % kk) in ent
     assert "Asum < 249.0f" in ent and "Asum < 4000.0f" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM 4000.0f" in src
     assert "(__float_as_uint(E) + 1u) & ~1u" in ent and "(__float_as_uint(E) + 1u) & ~1u" in src   # same flag encoding on both sides
