@@ -32,6 +32,10 @@
 //                 the second still moved something -- no stream is given up -- and in any case runs the
 //       scan      exclusive prefix sum of (blocks, dc[3], records) over the workgroups: with K2's local
 //                 scan, absolute block index, DC predictors and record ordinal at every sub-sequence entry.
+//   K1 + K2 in one kernel (k_sync_write) where it applies -- one image without restart markers on the compact stream, a
+//                 grid that is resident at once: a workgroup does K1's pass 0, publishes, adds up its predecessors' totals,
+//                 checks every assumption up to its own and writes (K2's core) from the bits and tables it has in LDS; the
+//                 launches above and K2 follow it and leave at once unless a check failed or a wait expired.
 //   K2  write     one lane per sub-sequence decodes its own symbols again from its true entry
 //                 state and writes what K4 reads -- the non-zero coefficients scattered into the cleared dense
 //                 buffer (natural order, absolute DC, quirk Q1 applied), or, compact stream, a 4-byte record per
