@@ -1669,18 +1669,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         k1_wu = wu;
         k1_own = have && t >= wu;
         k1_as = s_edge[0];   // (what this workgroup's first own item decoded from: written before the body's last barrier)
-        // Published: every word carries its value and the call's number, stored and polled with relaxed atomics -- no
-        // fence anywhere (an agent-scope release writes this XCD's dirty L2 lines back, an acquire invalidates: per workgroup
-        // and per poll that doubled the kernel's time), no order between the words needed: each one says for itself
-        // whether it is there.
-        if (t == 0) {
-            const int4 w4 = a.wsum[g];         // (this thread's own stores above)
-            const uint32_t vals[PUB_WORDS] = {(uint32_t)w4.x, (uint32_t)w4.y, (uint32_t)w4.z, (uint32_t)w4.w, a.wrec[g],
-                                              (uint32_t)s_edge[1], (uint32_t)(s_edge[1] >> 32), (uint32_t)s_edge[0], (uint32_t)(s_edge[0] >> 32)};
-            for (uint32_t q = 0; q < PUB_WORDS; ++q)
-                __hip_atomic_store(&a.pub[(size_t)g * PUB_WORDS + q], (unsigned long long)vals[q] | ((unsigned long long)a.gen << 32), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // (the body's thread 0 has published the totals, the last exit state and the assumption: a.gen != 0)
     }
     const uint32_t gi = blockIdx.x, ti = threadIdx.x;
     // ---- every workgroup before this one: wait, add up, check ----

@@ -298,6 +298,17 @@
             __threadfence();
             __hip_atomic_store(&a.done[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (p == 0 && a.gen) {
+            // k_sync_write: published -- every word carries its value and the call's number, stored and polled with relaxed
+            // atomics: no fence anywhere (an agent-scope release writes this XCD's dirty L2 lines back, an acquire
+            // invalidates: per workgroup and per poll that doubled the kernel's time), no order between the words needed,
+            // each one says for itself whether it is there.  (From the registers: nothing is read back.)
+            const uint32_t vals[PUB_WORDS] = {(uint32_t)w.x, (uint32_t)w.y, (uint32_t)w.z, (uint32_t)w.w, wr,
+                                              (uint32_t)last, (uint32_t)(last >> 32), (uint32_t)s_edge[0], (uint32_t)(s_edge[0] >> 32)};
+            for (uint32_t q = 0; q < PUB_WORDS; ++q)
+                __hip_atomic_store(&a.pub[(size_t)g * PUB_WORDS + q], (unsigned long long)vals[q] | ((unsigned long long)a.gen << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (p == 0) {
             // nothing is verified before pass 1
             if (!known) atomicAdd(&a.meta->moved[0], 1u);
