@@ -214,3 +214,39 @@ def test_switching_streams_keeps_the_scratch_ordered(ctx):
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     for k in range(6):
         assert np.array_equal(outs[k].cpu().numpy(), want), k
+
+
+def test_one_kernel_path_beside_another_context():
+    """k_sync_write waits for workgroups with smaller indices: that must hold up when another context's kernels share the chip
+    and its grid is not resident all at once.  Two contexts on two streams, two pictures, four calls in flight each, every
+    output compared (tools/fused_two_streams.py is the long version)."""
+    import torch
+    import libkpeg_amd as K
+    pics = [T.synth_jpeg(2560, 1472, seed=31, quality=75, sigma=6.0), T.synth_jpeg(1920, 1088, seed=32, quality=80, sigma=4.0)]
+    ctxs, frames, bufs, outs, want = [], [], [], [], []
+    for d in pics:
+        p = T.oracle_parse(d)
+        st, w = T.oracle_decode(d)
+        c = K.Context(0)
+        assert c.lib.kpeg_hip_debug_set(c._h, 7, 2) == 0     # the compact stream, so that the one-kernel path applies
+        stream = torch.cuda.Stream()
+        c.set_stream(stream.cuda_stream)
+        ctxs.append((c, stream))
+        frames.append(T.make_frame(p))
+        bufs.append(torch.frombuffer(bytearray(p.scan), dtype=torch.uint8).cuda())
+        outs.append([torch.zeros(w.shape, dtype=torch.uint8, device="cuda") for _ in range(4)])
+        want.append(w)
+    torch.cuda.synchronize()
+    for rnd in range(6):
+        for k in range(4):
+            for i, (c, _) in enumerate(ctxs):
+                c.decode_scan_dev(frames[i], bufs[i].data_ptr(), bufs[i].numel(), outs[i][k].data_ptr())
+        for c, _ in ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+        for i in range(2):
+            for k in range(4):
+                assert np.array_equal(outs[i][k].cpu().numpy(), want[i]), (rnd, i, k)
+                outs[i][k].zero_()
+        torch.cuda.synchronize()   # (the zeroing runs on torch's stream, the decodes on their own)
+    assert [int(c.timings()["sync_rounds"]) for c, _ in ctxs] == [1, 1], "the one-kernel path was not taken"
