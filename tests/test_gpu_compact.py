@@ -162,3 +162,47 @@ def test_corrupt_streams_stay_inside_the_buffers(ctx):
     assert failed > 10
     assert np.array_equal(ctx.decode_scan(frame, p.scan), want)
     ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+
+
+def test_huge_blocks_split_over_lanes_and_workgroups_after_another_picture(ctx):
+    """Blocks whose bound is +inf (A >= 4000) and which are split over sub-sequences and workgroups, on the one-kernel
+    path (k_sync_write makes no presets): their bound must be written by whoever settles the block, not left as the
+    previous picture of the same size wrote it.  The picture before has the same blocks WITHOUT the huge terms, i.e.
+    finite bounds in exactly those slots."""
+    w, h = 2048, 1024
+    nmcu = (w // 8) * (h // 8)
+    base = T.synth_jpeg(w, h, seed=31, quality=75, sigma=6.0)
+    p0 = T.oracle_parse(base)
+    rc, coef = T.oracle_entropy(p0)
+    assert rc == 0
+    zz = T.zz_table()
+    qn = np.zeros((2, 64), np.uint16)
+    qn[:, zz] = p0.qt[:2]
+    qn[:, zz[5:10]] = 255                      # the five zig-zag positions the huge terms use
+    coef = coef.copy()
+    coef[:, :, 5:10] = 0
+    plain = T.encode_coefs(coef, w, h, qn[0], qn[1])
+    rng = np.random.default_rng(9)
+    big = coef.copy()
+    sel = np.arange(1, nmcu, 3)
+    big[sel, 0, 5:9] = rng.choice(np.array([-1000, -700, 700, 1000], np.int16), size=(sel.size, 4))
+    huge = T.encode_coefs(big, w, h, qn[0], qn[1])
+    assert len(T.oracle_parse(huge).scan) * 8 < 3 * w * h, "must stay on the sparse (96-bit) path"
+    st0, want0 = T.oracle_decode(plain)
+    st1, want1 = T.oracle_decode(huge)
+    assert st0 == T.DECODE_DONE and st1 == T.DECODE_DONE
+    pp, ph = T.oracle_parse(plain), T.oracle_parse(huge)
+    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 2) == 0
+    try:
+        for fused in (1, 0):
+            assert ctx.lib.kpeg_hip_debug_set(ctx._h, 9, fused) == 0
+            for rep in range(2):
+                assert np.array_equal(ctx.decode_scan(T.make_frame(pp), pp.scan), want0), (fused, rep, "plain")
+                got = ctx.decode_scan(T.make_frame(ph), ph.scan)
+                if fused:
+                    assert int(ctx.timings()["sync_rounds"]) == 1, "k_sync_write did not finish this call itself"
+                bad = np.argwhere(got != want1)
+                assert bad.size == 0, "fused %d rep %d: first mismatches (y,x,c) %s of %d" % (fused, rep, bad[:8].tolist(), len(bad))
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
