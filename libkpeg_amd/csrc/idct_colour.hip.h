@@ -89,6 +89,7 @@ struct IdctParams {
     const uint32_t* mcu_start;    // [MCUs + 1] first record of every MCU (a tile's records: [mcu_start[8 tile], mcu_start[8 tile + 8]))
     uint32_t rec_cap;             // records the buffer holds (bounds what a corrupt table can make a wavefront read)
     uint8_t* umask;               // [ntiles][64] unsafe-pixel mask: written by k_idct_colour_fast, read by k_fixup (ntiles rounded up to whole chunks of k_fixup)
+    uint8_t* urows;               // [ntiles][64][UROW_BYTES] what K4 knows about the pixel rows that have a marked pixel (only those are written): see UROW_BYTES
 };
 
 constexpr uint32_t KPEG_STATUS_WORDS = 16 + 256 + 64 + 16;   // [1] error flags, [2] K1 passes, [3] + [272..335] end-of-call tickets, [16..271] counters, [336..351] K2 loop counts of KPEG_SYNC_STATS builds
@@ -586,6 +587,12 @@ __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, 
 
 constexpr int IMG_BYTES = 24 * 128;       // compact path: the tile's 24 blocks rebuilt in LDS, natural order, int16
 constexpr int UMASK_TILE_BYTES = 64;      // unsafe-pixel mask: one byte per lane of a tile (lane = MCU << 3 | pixel row), bit 7 - i = pixel column i
+// A lane whose pixel row has a marked pixel also leaves the row's rounded fast samples and which of them it vouches for:
+//   bytes [0, 48): [component][pixel column] the rounded fast sample (minus the level shift) as f16 (exact up to +-2048);
+//   bytes [48, 52): per component Y Cb Cr and for the G term one byte, bit 7 - i set = pixel column i is safe there.
+// Slot of lane l of tile t: urows + (t * 64 + l) * UROW_BYTES -- addressed by position, so nothing has to be counted or
+// agreed on between lanes; only marked rows are ever written or read (a few MB of the buffer's 4 KB per tile).
+constexpr int UROW_BYTES = 64;
 
 #ifdef KPEG_K4_STAMP
 __device__ unsigned long long g_k4_stamp[8192 * 4];
@@ -871,7 +878,9 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         // ties are structural: equal and opposite (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5
         // exactly); their signs are shifted into `ub`, one bit per pixel column.
         uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
-        uint32_t ub = 0;
+        uint32_t ubY = 0, ubB = 0, ubR = 0, ubG = 0;   // per component and for the G term: bit 7 - i = pixel column i is safe
+        uint32_t hp[3][4];                              // the rounded samples as f16 pairs
+        float py = 0.0f, pb = 0.0f, pr = 0.0f;          // the even column's, until its odd neighbour's are there
         // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
         auto pixel_loop = [&](auto with_wide) {
 #pragma unroll
@@ -911,14 +920,26 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
                         kg = 0x80000000u;   // G is exact here
                     }
                 }
-                const uint32_t safe = __float_as_uint(fy) & __float_as_uint(fb) & __float_as_uint(fr) & kg;
                 pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
                 pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
                 pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
 #if defined(KPEG_ABLATE_PUSH)
-                (void)safe;   // timing experiment: no unsafe-pixel arithmetic survives
+                (void)fy, (void)fb, (void)fr, (void)kg;   // timing experiment: no unsafe-pixel arithmetic survives
 #else
-                ub = __builtin_amdgcn_alignbit(ub, safe, 31);   // ub << 1 | sign of safe
+                // the signs into the four bytes: u << 1 | sign (one v_alignbit each, in place of the ANDs that used to merge them)
+                ubY = __builtin_amdgcn_alignbit(ubY, __float_as_uint(fy), 31);
+                ubB = __builtin_amdgcn_alignbit(ubB, __float_as_uint(fb), 31);
+                ubR = __builtin_amdgcn_alignbit(ubR, __float_as_uint(fr), 31);
+                ubG = __builtin_amdgcn_alignbit(ubG, kg, 31);
+                if (i & 1) {
+                    // two columns' rounded samples as an f16 pair (exact: integers, |.| <= 2048 wherever the bound is finite enough to matter;
+                    // k_fixup treats a larger one as unsafe)
+                    hp[0][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(py, ry));
+                    hp[1][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pb, rb));
+                    hp[2][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pr, rr));
+                } else {
+                    py = ry, pb = rb, pr = rr;
+                }
 #endif
             }
         };
@@ -936,7 +957,16 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             // this lane's byte of the tile's unsafe-pixel mask: bit 7 - i = pixel column i needs the reference-order evaluation
             uint32_t lane_off = (uint32_t)tid;
             asm volatile("" : "+v"(lane_off));
-            p.umask[(size_t)tile * UMASK_TILE_BYTES + lane_off] = active ? (uint8_t)(~ub & 0xFFu) : (uint8_t)0;
+            const uint32_t marked = active ? ~(ubY & ubB & ubR & ubG) & 0xFFu : 0u;
+            p.umask[(size_t)tile * UMASK_TILE_BYTES + lane_off] = (uint8_t)marked;
+            if (marked) {
+                // ... and what k_fixup needs to settle them: the row's rounded samples and the four bytes (stores under the lanes' own
+                // condition: no test the wavefront waits for)
+                uint4v* row = reinterpret_cast<uint4v*>(p.urows + ((size_t)tile * 64 + lane_off) * UROW_BYTES);
+                const uint4v h0 = {hp[0][0], hp[0][1], hp[0][2], hp[0][3]}, h1 = {hp[1][0], hp[1][1], hp[1][2], hp[1][3]}, h2 = {hp[2][0], hp[2][1], hp[2][2], hp[2][3]};
+                row[0] = h0, row[1] = h1, row[2] = h2;
+                reinterpret_cast<uint32_t*>(row)[12] = (ubY & 0xFFu) | ((ubB & 0xFFu) << 8) | ((ubR & 0xFFu) << 16) | (ubG << 24);
+            }
         }
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -981,23 +1011,22 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
 
 // ---- k_fixup: the marked pixels, in the reference's own order ---------------------------------------------------
 // K4 leaves one byte per lane and tile in the unsafe-pixel mask (bit 7 - i = pixel column i of pixel row `lane & 7` of MCU
-// `lane >> 3` of the tile).  Here a wavefront takes chunks of FX_CHUNK_TILES tiles of the mask (one 16-byte load per lane),
-// lists their marked pixels in LDS (popcount + wavefront scan: no atomics; what does not fill a batch of 64 waits for the
-// next chunk) and settles them one lane per pixel: the pixel's three samples as MCU::computeIDCT has them (MCU.cpp:184-198:
-// float accumulator, double products, u outer, v inner, zero terms leave the accumulator as it is), then performLevelShift
-// and convertYCbCrToRGB (colour_exact), and the three bytes stored over what K4 wrote.  Nothing but the position comes
-// from K4, so a pixel's safe components have to be evaluated as well:
-//   dense layout: the three blocks are read where K2 wrote them, in natural order as they stand (exact_sample_lane);
-//   compact stream: the records stand in stream order, block after block, in zig-zag order inside a block, and K2 notes
-//     every MCU's first one.  Step 1, every lane: one walk over its MCU's records adds the reference's own terms up in DOUBLE,
-//     in the order they come.  The reference's float accumulator takes one float rounding per non-zero AC term, so it ends within
-//     2^-24 A nnz of that sum (A = the block's sum of |terms|, sample units) -- less than the block's bound |E| = U A (nnz + 14.5),
-//     scaled down to the roundings that are the reference's own: where the double sum is farther than that from a rounding
-//     boundary the reference rounds as it does, whatever the order.  Step 2, the components that are not (ties, mostly):
-//     corner-only blocks (the sign of E: at most three records) by four terms in the reference's order; the others by their
-//     lane too -- the positions of the block's records in a 64-bit mask, the values stored in LDS at the rank of their
-//     position (= natural order), the mask walked; blocks with more than FX_SLOTS records by the whole wavefront
-//     (exact_sample_wave), one sample after the other.
+// `lane >> 3` of the tile) and, for the rows that have a marked pixel, the row's rounded fast samples with the components it
+// vouches for (UROW_BYTES).  Here a wavefront takes chunks of FX_CHUNK_TILES tiles of the mask, lists their marked pixels in
+// LDS (popcount + wavefront scan: no atomics; what does not fill a batch of 64 waits for the next chunk) and settles them one
+// lane per pixel: the components K4 does not vouch for are evaluated as MCU::computeIDCT has them (MCU.cpp:184-198: float
+// accumulator, double products, u outer, v inner, zero terms leave the accumulator as it is), the others keep K4's rounded
+// value, then performLevelShift and convertYCbCrToRGB (colour_exact) and the pixel's three bytes stored over what K4 wrote.
+//   corner-only blocks (the sign of the block's bound; nine in ten: ties of chroma blocks, equal and opposite (0,1)/(1,0) terms
+//     that cancel on the diagonal): four terms by the lane itself -- dense layout from the block's first two rows, compact
+//     stream from the MCU's first four (luma) or last seven (chroma) records, which hold a block of at most three whole;
+//   any other block: dense layout, as it stands in natural order (exact_sample_lane); compact stream, by its lane too -- the
+//     positions of the block's records in a 64-bit mask, the values stored in LDS at the rank of their position (= natural
+//     order), the mask walked -- and blocks with more than FX_SLOTS records by the whole wavefront (exact_sample_wave), one
+//     sample after the other.
+// (A version that took nothing but positions from K4 and evaluated all three components of every marked pixel -- an order-free
+// double sum first, the reference's order only where that sum lay within the block's bound of a rounding boundary -- was
+// bit-exact too and took 20 us: 96 % of the marked pixels are chroma ties whose luma block has most of the MCU's records.)
 // The call's last kernel: its last wavefront hands the status words to the host mirror (status_epilogue).
 #ifndef KPEG_FX_WAVES
 #define KPEG_FX_WAVES 16
@@ -1028,18 +1057,9 @@ __global__ __launch_bounds__(FX_THREADS) void k_fixup(IdctParams p, QTables qt)
     __shared__ double s_cos[64];
     __shared__ uint32_t s_wg[2];      // [0] wavefronts of this workgroup that are done, [1] pixels they settled
     __shared__ uint32_t s_take;       // chunks of this workgroup handed out so far
-    // compact stream, step 1: a batch's pixels as the term lanes see them
-    __shared__ double s_d_all[COMPACT ? FX_WAVES : 1][64 * 3];       // [pixel][block] the double sums
-    __shared__ uint32_t s_n_all[COMPACT ? FX_WAVES : 1][64 * 3];     // ... and the records counted
-    __shared__ uint32_t s_mark_all[COMPACT ? FX_WAVES : 1][4 * 64];  // four passes of 64 terms: the pixel + 1 that begins at a term, tagged with the round
-    __shared__ uint2 s_info_all[COMPACT ? FX_WAVES : 1][64];         // .x first record - first term, .y 3 MCU | row << 8 | column << 11
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    double* const s_d = s_d_all[COMPACT ? wave : 0];
-    uint32_t* const s_n = s_n_all[COMPACT ? wave : 0];
-    uint32_t* const s_mark = s_mark_all[COMPACT ? wave : 0];
-    uint2* const s_info = s_info_all[COMPACT ? wave : 0];
     uint32_t* const s_list = s_list_all[wave];
     int16_t* const s_val = s_val_all[COMPACT ? wave : 0];
     uint32_t* const s_coop = s_coop_all[COMPACT ? wave : 0];
@@ -1094,178 +1114,180 @@ __global__ __launch_bounds__(FX_THREADS) void k_fixup(IdctParams p, QTables qt)
     const float c0 = 0x1.6a09e6p-1f;
     uint32_t settled = 0;   // (wave-uniform)
     uint32_t nl = 0;        // entries in the list (wave-uniform)
-    uint32_t fx_tag = 0;    // tag of the last round of term passes (compact stream, step 1)
-    if constexpr (COMPACT) {
-        s_mark[lane] = 0u, s_mark[64 + lane] = 0u, s_mark[128 + lane] = 0u, s_mark[192 + lane] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-
     // One batch: list entries [first, first + 64), those below `end` valid.  entry = tile << 9 | lane of the tile << 3 | bit of its byte
     auto process = [&](uint32_t first, uint32_t end) {
         const bool valid = first + lane < end;
         const uint32_t ent = valid ? s_list[first + lane] : 0u;
         const uint32_t tile = min(ent >> 9, p.ntiles - 1);
-        const uint32_t g = (ent >> 6) & 7u, x = (ent >> 3) & 7u, y = 7u - (ent & 7u);   // MCU of the tile, pixel row, pixel column
+        const uint32_t Lt = (ent >> 3) & 63u;                                           // lane of K4's wavefront: MCU of the tile << 3 | pixel row
+        const uint32_t g = Lt >> 3, x = Lt & 7u, y = 7u - (ent & 7u);                   // MCU, pixel row, pixel column
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
         const size_t mcu = (size_t)trow * p.mcus_w + m0 + g;
+        // What K4 left for the pixel's row: the rounded fast samples and, per component, whether it vouches for them.  A sample beyond
+        // what f16 holds exactly counts as not vouched for.
         int S0 = 128, S1 = 128, S2 = 128;   // the three samples after the level shift
+        uint32_t need = 0;                  // bit c: component c is to be evaluated in the reference's order
+        float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+        if (valid) {
+            const uint8_t* row = p.urows + ((size_t)tile * 64 + Lt) * UROW_BYTES;
+            const uint32_t keys = reinterpret_cast<const uint32_t*>(row)[12];
+            const _Float16* h = reinterpret_cast<const _Float16*>(row);
+            const float f0 = (float)h[y], f1 = (float)h[8 + y], f2 = (float)h[16 + y];
+            S0 = (int)f0 + 128, S1 = (int)f1 + 128, S2 = (int)f2 + 128;
+            const uint32_t sh = 7u - y;
+            need = (((keys >> sh) & 1u) && fabsf(f0) < 2047.0f ? 0u : 1u) | (((keys >> (8 + sh)) & 1u) && fabsf(f1) < 2047.0f ? 0u : 2u) |
+                   (((keys >> (16 + sh)) & 1u) && fabsf(f2) < 2047.0f ? 0u : 4u);
+            struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };   // (one 12-byte load)
+            const F3 eb = *reinterpret_cast<const F3*>(p.ebound + mcu * 3);
+            e0 = eb.a, e1 = eb.b, e2 = eb.c;   // (their signs: the block is corner-only)
+        }
+        const double* const cx = s_cos + x * 8, * const cy = s_cos + y * 8;
+        // MCU::computeIDCT's sum (MCU.cpp:184-198) for a block that has nothing outside (0,0), (0,1), (1,0), (1,1), in its order; a zero
+        // term leaves the float accumulator as it is (x + (+-0) == x), so none needs a test.  cos((2x+1) 0 pi/16) == 1.0 exactly.
+        auto corner = [&](int dc, int v01, int v10, int v11, const uint32_t* qi) -> int {
+            const float fc00 = (c0 * c0) * (float)(dc * (int)qi[0]), fc01 = (c0 * 1.0f) * (float)(v01 * (int)qi[1]),
+                        fc10 = (1.0f * c0) * (float)(v10 * (int)qi[8]), fc11 = (float)(v11 * (int)qi[9]);
+            float sum = fc00;
+            sum = (float)((double)sum + (double)fc01 * cy[1]);
+            sum = (float)((double)sum + (double)fc10 * cx[1]);
+            sum = (float)((double)sum + ((double)fc11 * cx[1]) * cy[1]);
+            return level_shift((float)(0.25 * (double)sum));
+        };
         if constexpr (!COMPACT) {
-            if (valid) {
+            if (need) {
+                const uint32_t* c32 = reinterpret_cast<const uint32_t*>(p.coef) + mcu * 96;   // block c at + 32 c words: rows 0 and 1 at words 0 and 4
                 const uint4* blk = reinterpret_cast<const uint4*>(p.coef) + mcu * 3 * 8;
-                S0 = exact_sample_lane(blk, s_qi[0], s_cos, (int)x, (int)y);
-                S1 = exact_sample_lane(blk + 8, s_qi[1], s_cos, (int)x, (int)y);
-                S2 = exact_sample_lane(blk + 16, s_qi[1], s_cos, (int)x, (int)y);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (!(need & (1u << c))) continue;
+                    const float e = c == 0 ? e0 : (c == 1 ? e1 : e2);
+                    int S;
+                    if (__float_as_int(e) < 0) {
+                        const uint32_t w0 = c32[c * 32], w1 = c32[c * 32 + 4];
+                        S = corner((int)(short)(w0 & 0xFFFF), (int)w0 >> 16, (int)(short)(w1 & 0xFFFF), (int)w1 >> 16, s_qi[c ? 1 : 0]);
+                    } else {
+                        S = exact_sample_lane(blk + c * 8, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
+                    }
+                    if (c == 0) S0 = S;
+                    else if (c == 1) S1 = S;
+                    else S2 = S;
+                }
             }
             FX_T(3);
         } else {
-            uint32_t rs = 0, nr = 0, n0 = 0, n1 = 0, n2 = 0;
-            const uint32_t g3 = g * 3u;
+            // The MCU's records: [rs, rs + nr), block after block, zig-zag order inside a block (K2 notes every MCU's first one).
+            // Every load of this lane goes to an address of its own -- sixty-four cache lines per load instruction, which is what this
+            // kernel's time is made of -- so what lies together is loaded together: 2, 3 or 4 words per load.
+            struct __attribute__((packed, aligned(4))) U2 { uint32_t a, b; };
+            struct __attribute__((packed, aligned(4))) U4 { uint32_t a, b, c, d; };
+            uint32_t rs = 0, nr = 0;
             int dc0 = 0, dc1 = 0, dc2 = 0;
-            float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
-            uint32_t need = 0;   // bit c: component c still to be settled in the reference's order
-            const double* const cx = s_cos + x * 8, * const cy = s_cos + y * 8;
+            const uint32_t g3 = g * 3u;
             const uint2* const qc = &s_qc[0][0];
-            if (valid) {
-                const uint32_t a = p.mcu_start[mcu], b = p.mcu_start[mcu + 1];
-                nr = (b >= a && b <= p.rec_cap && b - a <= 3u * 63u) ? b - a : 0u;   // (a corrupt stream may leave anything in the table)
-                rs = a;
-                const int16_t* dcp = p.dc16 + mcu * 3;
-                dc0 = dcp[0], dc1 = dcp[1], dc2 = dcp[2];
-                const float* ebp = p.ebound + mcu * 3;
-                e0 = ebp[0], e1 = ebp[1], e2 = ebp[2];
-            }
-            // Step 1.  The batch's terms -- (pixel, record of its MCU) -- one per lane, as many passes as it takes, four passes a
-            // round: pixels of busy MCUs do not hold the others up.  Term t belongs to the last pixel whose first term is <= t: the
-            // pixels mark the lane their first term falls on and a prefix maximum carries them on.  The term's product goes to its
-            // pixel's sum of the record's block (LDS atomic add in double: the order does not matter here).
-            {
-                s_d[lane * 3] = 0.0, s_d[lane * 3 + 1] = 0.0, s_d[lane * 3 + 2] = 0.0;
-                s_n[lane * 3] = 0u, s_n[lane * 3 + 1] = 0u, s_n[lane * 3 + 2] = 0u;
-                const uint32_t tincl = wave_scan_incl(nr);
-                const uint32_t nterms = (uint32_t)__builtin_amdgcn_readlane((int)tincl, 63);
-                const uint32_t tfirst = tincl - nr;   // this pixel's first term
-                s_info[lane] = make_uint2(rs - tfirst, g3 | (x << 8) | (y << 11));
-                uint32_t carry = 0;   // the pixel + 1 the last term of the pass before belonged to
-                for (uint32_t t0 = 0; t0 < nterms; t0 += 256) {   // wave-uniform
-                    const uint32_t tag = (fx_tag += 256u);   // (never 0, never one this wavefront has used before: what the array holds from earlier rounds is not taken for a mark)
-                    {
-                        const uint32_t slot = tfirst - t0;
-                        if (nr && slot < 256u) s_mark[slot] = tag | (lane + 1u);   // (marks of earlier rounds carry other tags)
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    uint32_t ek[4], rk[4], ik[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        uint32_t v = s_mark[k * 64 + lane];
-                        v = (v & ~255u) == tag ? (v & 255u) : 0u;
-                        v = max(wave_scan_max(v), carry);
-                        carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-                        ek[k] = (v - 1u) & 63u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t t = t0 + (uint32_t)k * 64u + lane;
-                        const uint2 inf = s_info[ek[k]];
-                        ik[k] = inf.y;
-                        rk[k] = t < nterms ? p.rec[inf.x + t] : 31u;   // (block 31 does not exist: no term)
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t r = rk[k], c = (r & 31u) - (ik[k] & 31u), pos = (r >> 8) & 63u;
-                        const uint2 q = qc[(c ? 64u : 0u) + pos];
-                        const int F = __mul24((int)r >> 16, (int)q.x);                           // m_8x8block after MCU.cpp:110-112
-                        const float fc = __uint_as_float(q.y) * (float)F;                        // cc * (float)F, float multiply (MCU.cpp:189-192)
-                        const double td = ((double)fc * s_cos[((ik[k] >> 8) & 7u) * 8 + (pos >> 3)]) * s_cos[((ik[k] >> 11) & 7u) * 8 + (pos & 7u)];   // the reference's two double multiplies
-                        if (c < 3u) {
-                            (void)__hip_atomic_fetch_add(&s_d[ek[k] * 3 + c], td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            (void)__hip_atomic_fetch_add(&s_n[ek[k] * 3 + c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
+            if (need) {
+                const U2 ab = *reinterpret_cast<const U2*>(p.mcu_start + mcu);
+                nr = (ab.b >= ab.a && ab.b <= p.rec_cap && ab.b - ab.a <= 3u * 63u) ? ab.b - ab.a : 0u;   // (a corrupt stream may leave anything in the table)
+                rs = nr ? ab.a : 0u;
+                {
+                    // the three DC values: six bytes, inside the eight from the word they begin in
+                    const uintptr_t da = reinterpret_cast<uintptr_t>(p.dc16 + mcu * 3);
+                    const U2 dw = *reinterpret_cast<const U2*>(da & ~(uintptr_t)3);
+                    const unsigned long long dv = (((unsigned long long)dw.b << 32) | dw.a) >> ((da & 2u) * 8u);
+                    dc0 = (int)(short)(dv & 0xFFFF), dc1 = (int)(short)((dv >> 16) & 0xFFFF), dc2 = (int)(short)((dv >> 32) & 0xFFFF);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            FX_T(3);   // index, DC values, bounds, the terms
-            if (valid) {
-                n0 = s_n[lane * 3], n1 = s_n[lane * 3 + 1], n2 = s_n[lane * 3 + 2];
                 const uint32_t* rp = p.rec + rs;
-                // (0,0): cc * (float)(DC * Q00), both cosines 1.0
-                const double d0 = (double)((c0 * c0) * (float)(dc0 * (int)s_qi[0][0])) + s_d[lane * 3];
-                const double d1 = (double)((c0 * c0) * (float)(dc1 * (int)s_qi[1][0])) + s_d[lane * 3 + 1];
-                const double d2 = (double)((c0 * c0) * (float)(dc2 * (int)s_qi[1][0])) + s_d[lane * 3 + 2];
-                // roundl(0.25 d) is the reference's sample wherever 0.25 d is farther from n + 0.5 than the reference's own roundings can
-                // carry it: |E| (nnz + 0.5) / (nnz + 14.5) >= 2^-24 A nnz; 1e-9 covers the double sum's roundings (A < 4000 where E is finite;
-                // E = +inf: never far enough)
-                auto settle = [](double d, float e, uint32_t n, int& S) -> bool {
-                    const double v = 0.25 * d, fl = floor(v);
-                    const double lim = (double)(fabsf(e) * (((float)n + 0.5f) / ((float)n + 14.5f))) + 1e-9;
-                    S = (int)(fl + ((v - fl) > 0.5 ? 1.0 : 0.0)) + 128;
-                    return !(fabs((v - fl) - 0.5) > lim);
-                };
-                need = (settle(d0, e0, n0, S0) ? 1u : 0u) | (settle(d1, e1, n1, S1) ? 2u : 0u) | (settle(d2, e2, n2, S2) ? 4u : 0u);
-                // Step 2a.  Corner-only blocks: (0,1), (1,0), (1,1) are all a block has besides its DC value
-                auto corner = [&](uint32_t off, uint32_t n, int dc, const uint32_t* qi, int& S) {
-                    int v01 = 0, v10 = 0, v11 = 0;
-                    uint32_t r[3];
+                // Corner-only blocks (nine in ten of what gets here: ties of chroma blocks) have at most three records: the luma block's are
+                // the MCU's first, the chroma blocks' its last.  The first four and the last eight records say how many each block has as
+                // long as that is few, and hold them.
+                uint32_t hd[4], tl[8];
+                {
+                    const U4 h = *reinterpret_cast<const U4*>(rp);
+                    hd[0] = 0 < nr ? h.a : 31u, hd[1] = 1 < nr ? h.b : 31u, hd[2] = 2 < nr ? h.c : 31u, hd[3] = 3 < nr ? h.d : 31u;   // (block 31 does not exist)
+                    const uint32_t e8 = rs + nr >= 8u ? rs + nr - 8u : 0u;   // first of the eight
+                    const U4 ta = *reinterpret_cast<const U4*>(p.rec + e8), tb = *reinterpret_cast<const U4*>(p.rec + e8 + 4);
+                    const uint32_t tw[8] = {ta.a, ta.b, ta.c, ta.d, tb.a, tb.b, tb.c, tb.d};
 #pragma unroll
-                    for (uint32_t k = 0; k < 3; ++k) r[k] = k < n ? rp[off + k] : 0u;
+                    for (uint32_t k = 0; k < 8; ++k) tl[k] = (e8 + k >= rs && e8 + k < rs + nr) ? tw[k] : 31u;
+                }
+                // the luma block has fewer than four records if one of the first four is not its own
+                uint32_t lead = 0;
+                bool run = true;
 #pragma unroll
-                    for (uint32_t k = 0; k < 3; ++k) {
+                for (uint32_t k = 0; k < 4; ++k) {
+                    run = run && (hd[k] & 31u) == g3;
+                    lead += run ? 1u : 0u;
+                }
+                // the chroma blocks' records, counted among the last eight: all of them are there if a luma record (or no record at all) is
+                // among the eight too -- the records come block after block
+                uint32_t k2 = 0, k1 = 0, k0 = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t c = (tl[k] & 31u) - g3;
+                    k2 += c == 2u ? 1u : 0u;
+                    k1 += c == 1u ? 1u : 0u;
+                    k0 += (c == 0u || (tl[k] & 31u) == 31u) ? 1u : 0u;
+                }
+                const bool tail_known = k0 != 0;
+                auto pick = [&](const uint32_t* r, int n, uint32_t c, int& v01, int& v10, int& v11) {
+                    v01 = v10 = v11 = 0;
+                    for (int k = 0; k < n; ++k) {
                         const uint32_t pos = (r[k] >> 8) & 63u;
                         const int val = (int)r[k] >> 16;
-                        v01 = pos == 1 ? val : v01;
-                        v10 = pos == 8 ? val : v10;
-                        v11 = pos == 9 ? val : v11;
+                        const bool mine = (r[k] & 31u) - g3 == c;
+                        v01 = mine && pos == 1 ? val : v01;
+                        v10 = mine && pos == 8 ? val : v10;
+                        v11 = mine && pos == 9 ? val : v11;
                     }
-                    const float fc00 = (c0 * c0) * (float)(dc * (int)qi[0]), fc01 = (c0 * 1.0f) * (float)(v01 * (int)qi[1]),
-                                fc10 = (1.0f * c0) * (float)(v10 * (int)qi[8]), fc11 = (float)(v11 * (int)qi[9]);
-                    // MCU::computeIDCT's sum (MCU.cpp:184-198) over the four terms, in its order; a zero term leaves the float
-                    // accumulator as it is (x + (+-0) == x), so none needs a test.  cos((2x+1) 0 pi/16) == 1.0 exactly.
-                    float sum = fc00;
-                    sum = (float)((double)sum + (double)fc01 * cy[1]);
-                    sum = (float)((double)sum + (double)fc10 * cx[1]);
-                    sum = (float)((double)sum + ((double)fc11 * cx[1]) * cy[1]);
-                    S = level_shift((float)(0.25 * (double)sum));
                 };
-                if ((need & 1u) && __float_as_int(e0) < 0 && n0 <= 3) corner(0, n0, dc0, s_qi[0], S0), need &= ~1u;
-                if ((need & 2u) && __float_as_int(e1) < 0 && n1 <= 3) corner(n0, n1, dc1, s_qi[1], S1), need &= ~2u;
-                if ((need & 4u) && __float_as_int(e2) < 0 && n2 <= 3) corner(n0 + n1, n2, dc2, s_qi[1], S2), need &= ~4u;
+                int v01, v10, v11;
+                if ((need & 1u) && __float_as_int(e0) < 0 && lead <= 3) {
+                    pick(hd, 4, 0u, v01, v10, v11);
+                    S0 = corner(dc0, v01, v10, v11, s_qi[0]);
+                    need &= ~1u;
+                }
+                if ((need & 2u) && __float_as_int(e1) < 0 && tail_known && k1 <= 3) {
+                    pick(tl, 8, 1u, v01, v10, v11);
+                    S1 = corner(dc1, v01, v10, v11, s_qi[1]);
+                    need &= ~2u;
+                }
+                if ((need & 4u) && __float_as_int(e2) < 0 && tail_known && k2 <= 3) {
+                    pick(tl, 8, 2u, v01, v10, v11);
+                    S2 = corner(dc2, v01, v10, v11, s_qi[1]);
+                    need &= ~4u;
+                }
             }
-            FX_T(7);   // the sums looked at, corner-only blocks
-            // Step 2b.  Any other block, by its lane: every lane takes the first component it still has to settle; rounds until none has one
+            FX_T(3);   // the row K4 left, index, DC values, bounds, corner-only blocks
+            // Any other block, by its lane: the positions of the block's records in a 64-bit mask, the values stored in LDS at the rank of
+            // their position (= natural order), the mask walked.  Every lane takes the first component it still has to settle; rounds
+            // until none has one.
             uint32_t coop = 0;   // bit c: more records than a lane keeps -- by the whole wavefront below
             while (__ballot(need != 0)) {   // wave-uniform
                 if (need) {
                     const uint32_t c = need & 1u ? 0u : (need & 2u ? 1u : 2u);
                     need &= ~(1u << c);
-                    const uint32_t off = c == 0 ? 0u : (c == 1 ? n0 : n0 + n1), n = c == 0 ? n0 : (c == 1 ? n1 : n2);
-                    if (n > (uint32_t)FX_SLOTS) {
+                    const uint32_t* rp = p.rec + rs;
+                    unsigned long long mk = 0;
+                    for (uint32_t j0 = 0; j0 < nr; j0 += 4) {   // (the words behind the MCU's last record belong to the buffer: its slack)
+                        const U4 q4 = *reinterpret_cast<const U4*>(rp + j0);
+                        const uint32_t r[4] = {q4.a, q4.b, q4.c, q4.d};
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t pos = (r[k] >> 8) & 63u;
+                            mk |= (j0 + k < nr && (r[k] & 31u) - g3 == c && pos) ? 1ull << pos : 0ull;
+                        }
+                    }
+                    if ((uint32_t)__popcll(mk) > (uint32_t)FX_SLOTS) {
                         coop |= 1u << c;
                     } else {
-                        const uint32_t* rp = p.rec + rs + off;
-                        unsigned long long mk = 0;
-                        for (uint32_t j0 = 0; j0 < n; j0 += 4) {
-                            uint32_t r[4];
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k) r[k] = j0 + k < n ? rp[j0 + k] : 0u;   // (position 0: no bit)
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k) {
-                                const uint32_t pos = (r[k] >> 8) & 63u;
-                                mk |= pos ? 1ull << pos : 0ull;
-                            }
-                        }
-                        for (uint32_t j0 = 0; j0 < n; j0 += 4) {
-                            uint32_t r[4];
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k) r[k] = j0 + k < n ? rp[j0 + k] : 0u;
+                        for (uint32_t j0 = 0; j0 < nr; j0 += 4) {
+                            const U4 q4 = *reinterpret_cast<const U4*>(rp + j0);
+                            const uint32_t r[4] = {q4.a, q4.b, q4.c, q4.d};
 #pragma unroll
                             for (uint32_t k = 0; k < 4; ++k) {
                                 const uint32_t pos = (r[k] >> 8) & 63u;
                                 const uint32_t rank = (uint32_t)__popcll(mk & ((1ull << pos) - 1ull));
-                                if (pos) s_val[rank * 64u + lane] = (int16_t)((int)r[k] >> 16);   // (rank < n <= FX_SLOTS)
+                                if (j0 + k < nr && (r[k] & 31u) - g3 == c && pos) s_val[rank * 64u + lane] = (int16_t)((int)r[k] >> 16);   // (rank < FX_SLOTS)
                             }
                         }
                         const uint2* const q1 = qc + (c ? 64 : 0);
@@ -1290,18 +1312,14 @@ __global__ __launch_bounds__(FX_THREADS) void k_fixup(IdctParams p, QTables qt)
                 }
             }
             FX_T(4);   // blocks walked in natural order by their lane
-            // Step 2c.  Blocks with more records than that: one sample after the other, by the whole wavefront, lane = coefficient position
+            // Blocks with more records than that: one sample after the other, by the whole wavefront, lane = coefficient position
             unsigned long long w0 = __ballot((coop & 1u) != 0), w1 = __ballot((coop & 2u) != 0), w2 = __ballot((coop & 4u) != 0);
             while (w0 | w1 | w2) {   // wave-uniform
                 unsigned long long& mm = w0 ? w0 : (w1 ? w1 : w2);
                 const uint32_t c = w0 ? 0u : (w1 ? 1u : 2u);
                 const int L = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                const uint32_t n0L = (uint32_t)__builtin_amdgcn_readlane((int)n0, L), n1L = (uint32_t)__builtin_amdgcn_readlane((int)n1, L);
-                const uint32_t n2L = (uint32_t)__builtin_amdgcn_readlane((int)n2, L);
-                const uint32_t offL = c == 0 ? 0u : (c == 1 ? n0L : n0L + n1L);
-                const uint32_t nL = min(63u, c == 0 ? n0L : (c == 1 ? n1L : n2L));
-                const uint32_t r0L = (uint32_t)__builtin_amdgcn_readlane((int)rs, L) + offL;
+                const uint32_t nrL = (uint32_t)__builtin_amdgcn_readlane((int)nr, L), r0L = (uint32_t)__builtin_amdgcn_readlane((int)rs, L);
                 const uint32_t g3L = (uint32_t)__builtin_amdgcn_readlane((int)g3, L);
                 const int xL = __builtin_amdgcn_readlane((int)x, L), yL = __builtin_amdgcn_readlane((int)y, L);
                 const int dcL = __builtin_amdgcn_readlane(c == 0 ? dc0 : (c == 1 ? dc1 : dc2), L);
@@ -1309,8 +1327,8 @@ __global__ __launch_bounds__(FX_THREADS) void k_fixup(IdctParams p, QTables qt)
                 img16[lane] = (int16_t)(lane == 0 ? dcL : 0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (lane < nL) {
-                    const uint32_t r = p.rec[r0L + lane];
+                for (uint32_t j = lane; j < nrL; j += 64) {   // the MCU's records: this block's to their positions
+                    const uint32_t r = p.rec[r0L + j];
                     const uint32_t pos = (r >> 8) & 63u;
                     if ((r & 31u) - g3L == c && pos) img16[pos] = (int16_t)((int)r >> 16);
                 }

@@ -63,6 +63,8 @@ struct kpeg_hip_ctx {
     size_t tstart_cap = 0;
     void* d_umask = nullptr;    // K4's unsafe-pixel mask, 64 bytes per tile (k_idct_colour_fast writes it, k_fixup reads it)
     size_t umask_cap = 0;
+    void* d_urows = nullptr;    // ... and a slot per lane and tile for the rows that have a marked pixel (4 KB per tile, touched where marked only)
+    size_t urows_cap = 0;
     int fx_wgs_per_cu = 1;      // k_fixup's workgroups a CU holds at once
     int coef_layout = 0;       // test hook: 0 = chosen per call, 1 = always the dense layout, 2 = the compact stream wherever it is possible
     EntropyScratch ent;        // K0..K3 work buffers
@@ -258,6 +260,7 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     if (ctx->d_dc16) (void)hipFree(ctx->d_dc16);
     if (ctx->d_tstart) (void)hipFree(ctx->d_tstart);
     if (ctx->d_umask) (void)hipFree(ctx->d_umask);
+    if (ctx->d_urows) (void)hipFree(ctx->d_urows);
     entropy_scratch_free(&ctx->ent);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -433,8 +436,9 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     p.rec = compact ? (const uint32_t*)ctx->d_rec : nullptr;
     p.dc16 = compact ? (const int16_t*)ctx->d_dc16 : nullptr;
     p.mcu_start = compact ? (const uint32_t*)ctx->d_tstart : nullptr;
-    p.rec_cap = compact ? (uint32_t)std::min<size_t>(ctx->rec_cap / 4, 0xFFFFFFFFu) : 0u;
+    p.rec_cap = compact ? (uint32_t)std::min<size_t>(ctx->rec_cap / 4 - 16, 0xFFFFFFF0u) : 0u;   // (k_fixup reads up to four words from a record on: inside the buffer)
     p.umask = nullptr;
+    p.urows = nullptr;
     if (ctx->idct_mode == 1) {
         p.tiles_w = 0;
         p.ntiles = 0;
@@ -459,6 +463,8 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
         int rc = grow(ctx, &ctx->d_umask, &ctx->umask_cap, (size_t)nchunks * FX_CHUNK_TILES * UMASK_TILE_BYTES);
         if (rc) return rc;
         p.umask = (uint8_t*)ctx->d_umask;
+        if ((rc = grow(ctx, &ctx->d_urows, &ctx->urows_cap, (size_t)p.ntiles * 64 * UROW_BYTES))) return rc;
+        p.urows = (uint8_t*)ctx->d_urows;
         const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)ctx->k4_wgs_per_cu;
         const uint32_t want = (p.ntiles + K4_WAVES - 1) / K4_WAVES;   // at least a tile per wavefront
         const uint32_t grid = want < resident ? want : resident;

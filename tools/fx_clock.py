@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-PHASES = ["set-up", "mask+scan", "list", "terms", "lane blocks", "wave samples", "colour+store", "settle+corner"]
+PHASES = ["set-up", "mask+scan", "list", "row+corner", "lane blocks", "wave samples", "colour+store", "-"]
 
 
 def main():
