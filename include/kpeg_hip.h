@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KPEG_HIP_ABI_VERSION 3
+#define KPEG_HIP_ABI_VERSION 2
 
 enum {
     KPEG_HIP_OK = 0,
@@ -78,17 +78,14 @@ typedef struct kpeg_frame {
  * kpeg_hip_sync() when profiling is enabled.  0 for kernels that did not run. */
 typedef struct kpeg_hip_timings {
     float unstuff_ms;      /* K0: FF00 removal / restart-segment scan                        */
-    float huff_sync_ms;    /* K1: pass 0 of the self-synchronising sub-sequence decode; where K1 and K2 are one
-                              kernel (k_sync_write), that kernel                             */
-    float huff_scan_ms;    /*     K1's verifying and chained launches (the scan of the totals runs inside the
-                              last); behind k_sync_write they leave at once                  */
-    float huff_write_ms;   /* K2: coefficient-writing decode pass (behind k_sync_write: leaves at once) */
-    float dc_ms;           /*     launch gap between K2 and K4 (there is no DC kernel: the scan yields the predictors) */
-    float idct_ms;         /* K4: dequantise + IDCT + level shift + colour + tiled RGB store; marks unsafe pixels */
+    float huff_sync_ms;    /* K1: self-synchronising sub-sequence decode (all rounds)        */
+    float huff_scan_ms;    /*     prefix sums between K1 and K2                              */
+    float huff_write_ms;   /* K2: coefficient-writing decode pass                            */
+    float dc_ms;           /* K3: DC prediction prefix sum + Q1                              */
+    float idct_ms;         /* K4: dequantise + IDCT + level shift + colour + tiled RGB store */
     float total_ms;        /* first kernel start -> last kernel end                          */
-    uint32_t sync_rounds;  /* K1 launches that had work (1: k_sync_write finished the call itself) */
-    uint32_t exact_pixels; /* pixels that took the reference-order re-evaluation (k_fixup)    */
-    float fixup_ms;        /* k_fixup: the marked pixels in the reference's order (ABI 3)     */
+    uint32_t sync_rounds;  /* K1 rounds until every sub-sequence had synchronised            */
+    uint32_t exact_pixels; /* K4: pixels that took the reference-order re-evaluation         */
 } kpeg_hip_timings;
 
 /* ---- lifecycle ------------------------------------------------------------------------- */

@@ -16,7 +16,7 @@ HIP_LIB = os.environ.get("KPEG_HIP_LIB") or os.path.join(_HERE, "libkpeg_hip.so"
 HOST_LIB = os.path.join(_HERE, "libkpeg.so")
 CLI = os.path.join(_HERE, "kpeg")
 
-ABI_VERSION = 3
+ABI_VERSION = 2
 OK = 0
 E_ARG, E_DEVICE, E_TABLES, E_STREAM, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
@@ -46,7 +46,7 @@ class Frame(ctypes.Structure):
 class Timings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in
                 ("unstuff_ms", "huff_sync_ms", "huff_scan_ms", "huff_write_ms", "dc_ms", "idct_ms", "total_ms")] + \
-               [("sync_rounds", ctypes.c_uint32), ("exact_pixels", ctypes.c_uint32), ("fixup_ms", ctypes.c_float)]
+               [("sync_rounds", ctypes.c_uint32), ("exact_pixels", ctypes.c_uint32)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

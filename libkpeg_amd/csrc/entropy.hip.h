@@ -356,8 +356,8 @@ struct EntropyLaunch {
     uint32_t* d_rec = nullptr;
     uint32_t rec_cap = 0;
     int16_t* d_dc16 = nullptr;
-    uint32_t* d_mcu_start = nullptr;
-    uint32_t nstart = 0;    // entries of d_mcu_start minus one: the MCUs
+    uint32_t* d_tile_start = nullptr;
+    uint32_t ntiles = 0;
     unsigned long long spin_ticks = 0;   // bound of the waits between workgroups in 100 MHz ticks, 0 = defaults (test hook)
     uint32_t fault = 0;                  // fault injection (test hook): bit 0 K0's, bit 1 K1's workgroup 0 never publishes
     uint32_t gray = 0;                   // one-component stream (kpeg_frame::components == 1)
@@ -1240,8 +1240,8 @@ struct SyncArgs {
     int4* wsum;         // [nwg_cap] per-workgroup totals of cnt
     uint32_t* nrec;     // [nsub_cap] records (non-zero AC coefficients) of the run that produced X
     uint32_t* wrec;     // [nwg_cap] per-workgroup totals of nrec
-    uint32_t* mcu_start;  // compact coefficient stream (non-null): [nstart + 1] first record of every MCU, preset to 0 here
-    uint32_t nstart;      // ... the MCUs
+    uint32_t* tile_start;  // compact coefficient stream (non-null): [ntiles + 1] first record of every K4 tile, preset to 0 here
+    uint32_t ntiles;
     uint4* coef16;      // pass 0 clears the coefficient buffer, a slice per workgroup, behind its decode (dense layout only)
     uint64_t coef_n16;
     uint32_t* ebound;   // ... and presets K4's per-block bounds to +inf (a block K2 leaves out takes K4's exact path)
@@ -1409,9 +1409,9 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             // what pass 0 does behind its first decode, k_sync_write left undone: the presets (it has every entry written by the
             // one workgroup that owns it, or not at all), and the exchange slots its workgroups may have used
             const uint32_t nwg = (nsub + OWN - 1) / OWN;
-            const uint32_t tper = (a.nstart + 1 + nwg - 1) / nwg;
-            const uint32_t t0 = min(a.nstart + 1, g * tper), t1 = min(a.nstart + 1, t0 + tper);
-            for (uint32_t q = t0 + t; q < t1; q += SYNC_WG) a.mcu_start[q] = 0u;
+            const uint32_t tper = (a.ntiles + 1 + nwg - 1) / nwg;
+            const uint32_t t0 = min(a.ntiles + 1, g * tper), t1 = min(a.ntiles + 1, t0 + tper);
+            for (uint32_t q = t0 + t; q < t1; q += SYNC_WG) a.tile_start[q] = 0u;
             const uint32_t eper = (a.nblocks + nwg - 1) / nwg;
             const uint32_t e0 = min(a.nblocks, g * eper), e1 = min(a.nblocks, e0 + eper);
             for (uint32_t q = e0 + t; q < e1; q += SYNC_WG) a.ebound[q] = 0x7F800000u;
@@ -1527,9 +1527,8 @@ struct WriteArgs {
     uint32_t* rec;
     uint32_t rec_cap;
     int16_t* dc16;           // [blocks]
-    uint32_t* mcu_start;     // [nstart + 1] first record of every MCU (nstart = MCUs), preset to 0 by K1; K4 takes a tile's records from every
-                             // eighth entry, k_fixup a pixel's from its MCU's
-    uint32_t nstart;
+    uint32_t* tile_start;    // [ntiles + 1], preset to 0 by K1
+    uint32_t ntiles;
     uint32_t gray;           // one-component stream (extension, dense layout only): every block is block 0 of its MCU
     const uint8_t* scan;     // non-null: no K0 ran -- the sub-sequences are chunks of the byte-stuffed scan (stage_unstuff), nsub = nsub_host
     uint32_t scan_len;
@@ -1906,8 +1905,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.wsum = (int4*)S->d_wsum;
     sa.nrec = (uint32_t*)S->d_nrec;
     sa.wrec = sa.nrec + nsub_cap;
-    sa.mcu_start = L.d_mcu_start;
-    sa.nstart = L.nstart;
+    sa.tile_start = L.d_tile_start;
+    sa.ntiles = L.ntiles;
     sa.coef16 = (uint4*)L.d_coef;
     sa.coef_n16 = (uint64_t)L.nmcu * (L.sub420 ? 48 : 24);   // 384 bytes per MCU (4:2:0: 768)
     sa.ebound = (uint32_t*)L.d_ebound;
@@ -1946,8 +1945,8 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     wa.rec = L.d_rec;
     wa.rec_cap = L.rec_cap;
     wa.dc16 = L.d_dc16;
-    wa.mcu_start = L.d_mcu_start;
-    wa.nstart = L.nstart;
+    wa.tile_start = L.d_tile_start;
+    wa.ntiles = L.ntiles;
     wa.gray = L.gray;
     wa.scan = sa.scan;
     wa.scan_len = n;
@@ -1961,7 +1960,7 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     // at once unless it gave up.
     bool fuse = false;
     if constexpr (SB < SUBSEQ_DENSE) {
-        fuse = stuffed && L.d_mcu_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= L.fused_slots;
+        fuse = stuffed && L.d_tile_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= L.fused_slots;
         if (fuse) {
             void* const before = S->d_flags;
             if ((rc = ent_grow(&S->d_flags, &S->flags_cap, (size_t)nwg_cap * PUB_WORDS * sizeof(unsigned long long), L.stream, err))) return rc;
@@ -1978,13 +1977,13 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
         sa.pass = t;
         sa.chained = t == npass - 1 ? 1 : 0;
         if (L.sub420) hipLaunchKernelGGL((k_sync_pass<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
-        else if (L.d_mcu_start) hipLaunchKernelGGL((k_sync_pass<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
+        else if (L.d_tile_start) hipLaunchKernelGGL((k_sync_pass<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
         else hipLaunchKernelGGL((k_sync_pass<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
     }
     mark(2);
     mark(3);
     if (L.sub420) hipLaunchKernelGGL((k_write<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
-    else if (L.d_mcu_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
+    else if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else hipLaunchKernelGGL((k_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);
     mark(5);

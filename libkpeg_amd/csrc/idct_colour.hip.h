@@ -7,28 +7,29 @@
 //
 // Bit-exactness.  The reference evaluates every sample as a 64-term sum accumulated in
 // *float* in (u outer, v inner) order from double products; its rounding
-// cannot be reproduced by a fast transform.  So:
-//   (1) k_idct_colour_fast computes a fast separable f32 IDCT whose distance to the reference's float
-//       result is bounded rigorously per block (tools/idct_bound.py derives the constant), and
-//   (2) where the fast value lies within that bound of a rounding boundary (or the G term is too close
-//       to an integer for the f32 colour arithmetic) it only MARKS the pixel, one bit in a mask of 64
-//       bytes per tile; k_fixup, the next launch, evaluates the marked pixels in the reference's own
-//       order and stores their bytes over the fast ones.
+// cannot be reproduced by a fast transform.  The kernel therefore computes
+//   (1) a fast separable f32 IDCT whose distance to the reference's float result is
+//       bounded rigorously per block (tools/idct_bound.py derives the constant), and
+//   (2) only where the fast value lies within that bound of a rounding boundary (or the G
+//       term is too close to an integer for the f32 colour arithmetic), the reference-order
+//       evaluation itself: such pixels are queued in the tile loop and fixed up in passes,
+//       after their tile has been stored (see k_idct_colour_fast).
 // Blocks with no AC coefficient are exact in (1) by construction.
 //
-// Mapping (no MFMA: byte/short work, not a dense contraction; the kernel is bound by its instruction stream).
-//   * one workgroup of K4_WAVES wavefronts per CU; every wavefront an independent worker that takes tiles of
-//     8 MCUs (64 x 8 pixels) from the workgroup's range through a counter in LDS; 8 lanes per MCU.
+// Mapping (no MFMA: byte/short work, not a dense contraction; the kernel is bound by VALU issue,
+// and on gfx950 only add/sub/mul/fma/and/or/mov issue at 1.7 cycles, everything else at 2.7:
+// tools/ubench/valu_rate.hip).
+//   * one wavefront per workgroup, 8 lanes per MCU, 8 MCUs (64x8 pixels) per tile; the grid is the
+//     resident wavefronts, each walks tiles blockIdx.x, + gridDim.x, ...
 //   * lane j of an 8-lane group loads one 16-byte row of each component block
 //     (rows 0,2,4,6 on lanes 0-3, rows 1,3,5,7 on lanes 4-7): a wavefront's three
-//     global_load_dwordx4 cover 8 MCUs x 384 B = 3 KiB of contiguous coefficients -- or, compact stream, the
-//     tile's records (4 bytes per non-zero AC coefficient) are scattered into an LDS image of the 24 blocks first.
+//     global_load_dwordx4 cover 8 MCUs x 384 B = 3 KiB of contiguous coefficients.
 //   * row pass (over v) in registers: even/odd decomposition, 34 f32 ops per 8 samples;
 //     column pass (over u) across the 8 lanes with DPP: quad broadcasts feed 4-term
 //     even (lanes 0-3) / odd (lanes 4-7) sums, one row_half_mirror FMA combines them.
 //     Lane l ends up with pixel row l of the block: 8 pixels x 3 components.
 //   * colour conversion in f32/int-exact arithmetic (proven ranges), RGB bytes staged in an
-//     LDS tile (8 rows x 768 B, padded rows) and written back with 16-byte coalesced nontemporal stores.
+//     LDS tile (8 rows x 768 B, padded rows) and written back with 16-byte coalesced stores.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -86,10 +87,8 @@ struct IdctParams {
     // A tile is 8 consecutive MCUs of the stream (mcus_w is a multiple of 8 on this path), its records are contiguous.
     const uint32_t* rec;          // [31:16] value, [13:8] natural position, [4:0] block within the tile (0..23)
     const int16_t* dc16;          // [blocks] absolute DC of every block
-    const uint32_t* mcu_start;    // [MCUs + 1] first record of every MCU (a tile's records: [mcu_start[8 tile], mcu_start[8 tile + 8]))
+    const uint32_t* tile_start;   // [ntiles + 1] first record of every tile
     uint32_t rec_cap;             // records the buffer holds (bounds what a corrupt table can make a wavefront read)
-    uint8_t* umask;               // [ntiles][64] unsafe-pixel mask: written by k_idct_colour_fast, read by k_fixup (ntiles rounded up to whole chunks of k_fixup)
-    uint8_t* urows;               // [ntiles][64][UROW_BYTES] what K4 knows about the pixel rows that have a marked pixel (only those are written): see UROW_BYTES
 };
 
 constexpr uint32_t KPEG_STATUS_WORDS = 16 + 256 + 64 + 16;   // [1] error flags, [2] K1 passes, [3] + [272..335] end-of-call tickets, [16..271] counters, [336..351] K2 loop counts of KPEG_SYNC_STATS builds
@@ -262,7 +261,8 @@ __global__ __launch_bounds__(256) void k_idct_colour_exact_420(const int16_t* __
 #define KPEG_A_LIM 4000.0f
 // The sign bit carries one more fact about the block: set = every non-zero AC coefficient sits at
 // (0,1), (1,0) or (1,1).  Those blocks produce nearly all true ties (equal and opposite (0,1)/(1,0)
-// terms cancel on the diagonal).  (K4 reads the magnitude only; the sign is kept for tools and tests.)
+// terms cancel on the diagonal), and their reference-order sum has at most four terms, which the
+// lane that holds the pixel's queue entry evaluates itself in the fix-up pass (exact_corner).
 __device__ __forceinline__ float block_ebound(float A, int nnz_ac, bool chroma, bool corner_only)
 {
     if (!(A < KPEG_A_LIM)) return __builtin_inff();
@@ -306,6 +306,7 @@ typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) uint4v;  // 
 constexpr int TILE_MCUS = 8;                    // MCUs per wavefront iteration (8 lane groups)
 constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 192
 constexpr int TILE_ROW_STRIDE = 208;            // padded: 13 x 16 bytes, conflict-free b64 writes across rows
+constexpr int QUEUE_CAP = 64;                   // queue entries per wavefront (fix-ups run from QUEUE_FLUSH entries on); pixels beyond go to the overflow list
 #ifndef KPEG_K4_WAVES
 #define KPEG_K4_WAVES 16
 #endif
@@ -521,7 +522,31 @@ __device__ __forceinline__ uint32_t pk_u8(float v, uint32_t sel, uint32_t old)
     return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, old);  // saturating float -> byte `sel` of old
 }
 
-// ---- reference-order evaluation of single samples (k_fixup) -------------------------------------
+// ---- reference-order evaluation of single samples (the fix-up passes) ---------------------------
+// Value of one sample of a block whose non-zero coefficients all lie in the 2x2 low-frequency corner:
+// MCU::computeIDCT's sum (MCU.cpp:184-198) restricted to the terms (0,0), (0,1), (1,0), (1,1) in that order --
+// the others are zero and leave the float accumulator unchanged, as do zero terms among these four
+// (x + (+-0) == x), so no test is needed.  cos((2x+1)*0*pi/16) == 1.0 exactly.
+//   w0 / w1: the words holding coefficients (0,0),(0,1) / (1,0),(1,1); q..: the four quantisers;
+//   cx1 = cosT[x][1], cy1 = cosT[y][1].  Returns roundl(ic) as a float (the sample minus the level shift).
+// One lane per sample: nearly all unsafe pixels are of this kind (structural ties, see the kernel).
+__device__ __forceinline__ float exact_corner(uint32_t w0, uint32_t w1, uint32_t q00, uint32_t q01, uint32_t q10, uint32_t q11,
+                                              double cx1, double cy1)
+{
+    const float c0 = 0x1.6a09e6p-1f;  // (float)(1/sqrt 2)
+    const int F00 = (int)(short)(w0 & 0xFFFF) * (int)q00, F01 = ((int)w0 >> 16) * (int)q01;
+    const int F10 = (int)(short)(w1 & 0xFFFF) * (int)q10, F11 = ((int)w1 >> 16) * (int)q11;
+    const float fc00 = (c0 * c0) * (float)F00, fc01 = (c0 * 1.0f) * (float)F01, fc10 = (1.0f * c0) * (float)F10,
+                fc11 = (float)F11;
+    float sum = fc00;                                              // (float)(0.0 + fc00 * 1.0 * 1.0)
+    sum = (float)((double)sum + (double)fc01 * cy1);              // ((double)fc01 * 1.0) * cy1
+    sum = (float)((double)sum + (double)fc10 * cx1);              // ((double)fc10 * cx1) * 1.0
+    sum = (float)((double)sum + ((double)fc11 * cx1) * cy1);
+    const float ic = (float)(0.25 * (double)sum);
+    const float t = truncf(ic), fr = ic - t;
+    return t + (fr >= 0.5f ? 1.0f : 0.0f) - (fr <= -0.5f ? 1.0f : 0.0f);  // roundl: half away from zero
+}
+
 // One sample of any block, evaluated by the whole wavefront: lane p owns coefficient position p = u*8+v
 // (row-major = the reference's loop order) and computes its product term; the float accumulation then walks
 // the non-zero lanes in order.  fc: cc * (float)(coefficient * Q) of this lane's position; x, y wave-uniform.
@@ -585,14 +610,31 @@ __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, 
     return level_shift((float)(0.25 * (double)sum));
 }
 
+#ifndef KPEG_PUSH_GROUP
+#define KPEG_PUSH_GROUP 4           // pixel columns per unsafe-pixel test, dense layout (measured 1 / 2 / 4: 68.9 / 65.3 / 64.0 us)
+#endif
+#ifndef KPEG_PUSH_GROUP_COMPACT
+#define KPEG_PUSH_GROUP_COMPACT 2   // ... compact stream (69.0 / 68.1 / 71.3 us: four keep too many registers live there)
+#endif
+#ifndef KPEG_K4_STASH_DENSE
+#define KPEG_K4_STASH_DENSE 0   // dense layout: 1 = queue entries carry their blocks' corner words too (six lane shuffles per tile and six
+                                // more VGPRs: measured no gain); 0 = the fix-up pass loads them from the coefficient buffer
+#endif
+#ifndef KPEG_K4_CHROMA2
+#define KPEG_K4_CHROMA2 0
+#endif
+#ifndef KPEG_K4_LUMA4
+#define KPEG_K4_LUMA4 0
+#endif
+#ifndef KPEG_QUEUE_FLUSH
+#define KPEG_QUEUE_FLUSH 32
+#endif
+constexpr int QUEUE_FLUSH = KPEG_QUEUE_FLUSH;   // queued pixels that make a fix-up pass worth its fixed cost
+constexpr int OVER_CAP = TILE_MCUS * 64 - (QUEUE_CAP - QUEUE_FLUSH);   // a tile starts with at least QUEUE_CAP - QUEUE_FLUSH free entries
+constexpr int QUEUE_WORDS = 8;    // per queued pixel: position, 3 rounded samples, 3 keys (>= 0: that component is unsafe), pad
+constexpr int QUEUE_WORDS_COMPACT = 16;   // ... + words 8..13: the 2x2 corner coefficients of the pixel's three blocks (the compact
+                                          // stream has no block to read them from later)
 constexpr int IMG_BYTES = 24 * 128;       // compact path: the tile's 24 blocks rebuilt in LDS, natural order, int16
-constexpr int UMASK_TILE_BYTES = 64;      // unsafe-pixel mask: one byte per lane of a tile (lane = MCU << 3 | pixel row), bit 7 - i = pixel column i
-// A lane whose pixel row has a marked pixel also leaves the row's rounded fast samples and which of them it vouches for:
-//   bytes [0, 48): [component][pixel column] the rounded fast sample (minus the level shift) as f16 (exact up to +-2048);
-//   bytes [48, 52): per component Y Cb Cr and for the G term one byte, bit 7 - i set = pixel column i is safe there.
-// Slot of lane l of tile t: urows + (t * 64 + l) * UROW_BYTES -- addressed by position, so nothing has to be counted or
-// agreed on between lanes; only marked rows are ever written or read (a few MB of the buffer's 4 KB per tile).
-constexpr int UROW_BYTES = 64;
 
 #ifdef KPEG_K4_STAMP
 __device__ unsigned long long g_k4_stamp[8192 * 4];
@@ -603,26 +645,26 @@ __device__ unsigned long long g_k4_stamp[8192 * 4];
 // wavefronts of one SIMD finished one after the other -- first 38 us, last 54-66 us, the SIMD two-thirds idle at the end
 // (profiles/r02: per-wavefront stamps) -- whereas wavefronts that take tiles as they go all finish together.
 //
-// Pixels whose fast value cannot be trusted (within the block's bound of a rounding boundary, or a G term too close to an
-// integer) are only MARKED here: every lane shifts the sign of its pixels' `safe` word into one byte per tile (no test, no
-// branch, no queue: one v_alignbit per pixel in place of the AND that used to gather a group's flags) and stores it to
-// the unsafe-pixel mask, 64 bytes per tile.  k_fixup, the launch behind this one, walks the mask and re-evaluates every
-// marked pixel in the reference's own order from the coefficients -- all three components, so nothing but the position has
-// to be handed over.  Rounds 1 and 2 queued such pixels in LDS from inside the pixel loop and fixed them up at the end of
-// the wavefront's tiles: a scalar branch on a vector compare per group of pixel columns, the queue pushes and the fix-up
-// passes were 25 of the kernel's 69 us (profiles/r02_h).
-#ifdef KPEG_K4_WPE
-#define KPEG_K4_OCC __attribute__((amdgpu_waves_per_eu(KPEG_K4_WPE, KPEG_K4_WPE)))   // experiments: several smaller workgroups per CU
-#else
-#define KPEG_K4_OCC
-#endif
+// Pixels whose fast value cannot be trusted (within the block's bound of a rounding boundary, or a G term too
+// close to an integer) are only *noted* in the tile loop: their position goes to a small queue in LDS.  Once the
+// tiles they belong to have been written out, a fix-up pass evaluates them in the reference's own order, one lane
+// per (pixel, component), and patches the three bytes in global memory.  Handling them where they are found -- a few
+// lanes of a wavefront, several times per tile -- cost 37 % of the kernel's time (profiles/r01_g: 0.103 -> 0.065 ms with
+// the handling compiled out).
 template <bool COMPACT>
-__global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(IdctParams p, QTables qt)
+__global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, QTables qt)
 {
+    constexpr int QW = (COMPACT || KPEG_K4_STASH_DENSE) ? QUEUE_WORDS_COMPACT : QUEUE_WORDS;   // entries that stash the blocks' corner words are twice as long
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_all[K4_WAVES][8 * TILE_ROW_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_queue_all[K4_WAVES][QUEUE_CAP * QW];
     __shared__ __attribute__((aligned(16))) uint32_t s_img_all[COMPACT ? K4_WAVES : 1][IMG_BYTES / 4];
+    __shared__ uint16_t s_over_all[K4_WAVES][OVER_CAP];   // unsafe pixels a tile has beyond the queue's room: bits [11:0] of the position word (the
+                                            // fix-up pass that takes them runs before the next tile: the tile is known)
     __shared__ __attribute__((aligned(16))) float s_m[2][64];     // AC input scales, natural order
+    __shared__ __attribute__((aligned(16))) uint32_t s_qi[2][64]; // quantisers (exact dequantisation in the fix-up pass)
+    __shared__ double s_cos[64];
     __shared__ uint32_t s_next;       // next tile of this workgroup's range to hand out
+    __shared__ uint32_t s_wg[2];      // [0] wavefronts of this workgroup that are done, [1] unsafe pixels they counted
 
 #ifdef KPEG_K4_STAMP
     // diagnostic build only (tools/k4_clock.py): the shader clock this kernel runs at = d(s_memtime) / d(s_memrealtime) x 100 MHz
@@ -631,7 +673,9 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
     const int tid = threadIdx.x & 63;   // lane of the wavefront
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint8_t* const s_tile = s_tile_all[wave];
+    uint32_t* const s_queue = s_queue_all[wave];
     uint32_t* const s_img = s_img_all[COMPACT ? wave : 0];
+    uint16_t* const s_over = s_over_all[wave];
     const int lane8 = tid & 7;          // lane within the MCU group = output pixel row
     const int grp = tid >> 3;           // MCU within the tile, 0..7
     const int u = lane8 < 4 ? 2 * lane8 : 2 * (lane8 - 4) + 1;  // coefficient row this lane loads
@@ -639,8 +683,13 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
     if (threadIdx.x < 128) {
         const int t = threadIdx.x >> 6, k = threadIdx.x & 63;
         s_m[t][k] = 0.25f * cc_of(k >> 3, k & 7) * (float)qt.q[t][k];
-    } else if (threadIdx.x == 128) {
+        s_qi[t][k] = qt.q[t][k];
+    } else if (threadIdx.x < 192) {
+        s_cos[tid] = c_cos[tid];
+    } else if (threadIdx.x == 192) {
         s_next = 0;
+        s_wg[0] = 0;
+        s_wg[1] = 0;
     }
     // this workgroup's tiles: [wg_tile0, wg_tile0 + wg_ntiles)
     const uint32_t wg_tile0 = (uint32_t)(((unsigned long long)p.ntiles * blockIdx.x) / gridDim.x);
@@ -727,12 +776,268 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         }
     };
 
+    uint32_t dbg_count = 0;   // experiments (KPEG_COUNT_*): reported in place of the unsafe-pixel count
+
+    // Fix-up passes.  A queue entry is a pixel of one of this wavefront's tiles:
+    //   word 0: [2:0] MCU within the tile, [5:3] pixel row, [8:6] pixel column, [11:9] component blocks that are
+    //           corner-only (the sign of their bound), [31:12] the tile's number k inside the workgroup's range (tile = wg_tile0 + k);
+    //   words 1..3: the three rounded fast samples (minus the level shift); words 4..6: their keys (>= 0: unsafe).
+    // nq queued entries, then nover pixels of the overflow list: position words only (a tile with more unsafe pixels
+    // than the queue had room for: clusters of ties, adversarial input), all components to be evaluated.  One lane per entry.  Unsafe components of corner-only blocks are settled by the lane itself
+    // with the four-term sum; the others (a few per wavefront) by the whole wavefront, one after the other; the lane
+    // then converts and stores its pixel.
+    // The tiles concerned have been written out by this wavefront before.
+    auto run_fixups = [&](uint32_t nq, uint32_t nover, uint32_t over_k) {
+        uint32_t lane = (uint32_t)tid;
+        asm volatile("" : "+v"(lane));   // nothing of a fix-up pass is to be computed ahead of the tile loop and kept in registers
+        const uint32_t total = nq + nover;
+        const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
+        for (uint32_t base = 0; base < total; base += 64) {
+            const uint32_t e = base + lane;
+            const bool valid = e < total;
+            uint32_t pos = 0;
+            float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, f0 = -1.0f, f1 = -1.0f, f2 = -1.0f;
+            if (valid) {
+                if (e < nq) {
+                    const uint4v a = *reinterpret_cast<const uint4v*>(s_queue + e * QW);
+                    const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 4);
+                    pos = a.x;
+                    r0 = __uint_as_float(a.y), r1 = __uint_as_float(a.z), r2 = __uint_as_float(a.w);
+                    f0 = __uint_as_float(b.x), f1 = __uint_as_float(b.y), f2 = __uint_as_float(b.z);
+                } else {
+                    pos = (uint32_t)s_over[e - nq] | (over_k << 12);
+                    f0 = f1 = f2 = 1.0f;
+                }
+            }
+            const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
+            const uint32_t tile = wg_tile0 + (pos >> 12);
+            const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
+            const uint32_t m0 = tcol * TILE_MCUS;
+            const uint32_t mcu = trow * p.mcus_w + m0 + g;
+            const bool need0 = f0 >= 0.0f, need1 = f1 >= 0.0f, need2 = f2 >= 0.0f;
+            // corner-only blocks: the two words such a block consists of
+#ifdef KPEG_FX_SKIP_CORNER
+            const bool cn0 = false, cn1 = false, cn2 = false;
+#else
+            // A queue entry carries the corner words of its three blocks (stashed when it was pushed: no load, no memory latency
+            // in this pass); an overflow-list pixel has none: dense layout -> two 4-byte loads per block, compact stream -> the
+            // general way (from the tile's image).
+            const bool from_queue = valid && e < nq && (COMPACT || KPEG_K4_STASH_DENSE);
+            const bool stashed = !COMPACT || from_queue;
+            const bool cn0 = need0 && (pos & (1u << 9)) && stashed, cn1 = need1 && (pos & (1u << 10)) && stashed, cn2 = need2 && (pos & (1u << 11)) && stashed;
+#endif
+            uint32_t w00 = 0, w01 = 0, w10 = 0, w11 = 0, w20 = 0, w21 = 0;
+            if (from_queue) {
+                const uint4v cw = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 8);
+                const uint2 cw2 = *reinterpret_cast<const uint2*>(s_queue + e * QW + 12);
+                w00 = cw.x, w01 = cw.y, w10 = cw.z, w11 = cw.w, w20 = cw2.x, w21 = cw2.y;
+            } else if constexpr (!COMPACT) {
+                const uint32_t* c32 = reinterpret_cast<const uint32_t*>(p.coef) + (size_t)mcu * 96;
+                if (cn0) w00 = c32[0], w01 = c32[4];
+                if (cn1) w10 = c32[32], w11 = c32[36];
+                if (cn2) w20 = c32[64], w21 = c32[68];
+            }
+            // the others: wave-uniform lists of (lane, component)
+            unsigned long long g0 = __ballot(need0 && !cn0), g1 = __ballot(need1 && !cn1), g2 = __ballot(need2 && !cn2);
+#ifdef KPEG_FX_SKIP_COOP
+            g0 = g1 = g2 = 0;
+#endif
+            auto pop = [](unsigned long long& m0_, unsigned long long& m1_, unsigned long long& m2_, uint32_t& c, uint32_t& L) {
+                unsigned long long& mm = m0_ ? m0_ : (m1_ ? m1_ : m2_);
+                c = m0_ ? 0u : (m1_ ? 1u : 2u);
+                L = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+            };
+            // The coefficient at position `lane` of block c of MCU mcuL (wave-uniform arguments), for the samples the whole
+            // wavefront evaluates.  Dense layout: one coalesced 128-byte load.  Compact stream: from the tile's image in LDS --
+            // only pixels of the tile that was computed last get here (the overflow list, settled before the next tile;
+            // queued pixels had their non-corner samples settled by resolve_noncorner while their tile's image stood).
+            auto fetch_coef = [&](uint32_t mcuL, uint32_t c, int) -> int {
+                if constexpr (!COMPACT) {
+                    return p.coef[((size_t)mcuL * 3 + c) * 64 + lane];
+                } else {
+                    const uint16_t* img16 = reinterpret_cast<const uint16_t*>(s_img);
+                    return (int)(int16_t)img16[((mcuL & (TILE_MCUS - 1)) * 3 + c) * 64 + lane];
+                }
+            };
+#ifndef KPEG_COOP_BATCH
+#define KPEG_COOP_BATCH 2
+#endif
+            constexpr int BATCH = KPEG_COOP_BATCH;
+            const bool many = __popcll(g0) + __popcll(g1) + __popcll(g2) > BATCH;   // wave-uniform
+#if defined(KPEG_COUNT_COOP)
+            dbg_count += __popcll(g0) + __popcll(g1) + __popcll(g2);
+#elif defined(KPEG_COUNT_MANY)
+            dbg_count += many ? 1u : 0u;
+#elif defined(KPEG_COUNT_FLUSH)
+            dbg_count += 1u;
+#elif defined(KPEG_COUNT_CORNER)
+            dbg_count += __popcll(__ballot(cn0)) + __popcll(__ballot(cn1)) + __popcll(__ballot(cn2));
+#endif
+            // a batch of those: one coalesced 128-byte load per sample, all in flight together with the corner words
+            // (one memory latency per pass -- at the end of a wavefront's life nothing hides it)
+            int cf[BATCH];
+            unsigned long long a0 = g0, a1 = g1, a2 = g2;
+            if (!many) {
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    cf[k] = 0;
+                    if (a0 | a1 | a2) {
+                        uint32_t c, L;
+                        pop(a0, a1, a2, c, L);
+                        const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
+                        cf[k] = fetch_coef(mcuL, c, k);
+                    }
+                }
+            }
+            const double cx1 = s_cos[x * 8 + 1], cy1 = s_cos[y * 8 + 1];
+            if (cn0) r0 = exact_corner(w00, w01, s_qi[0][0], s_qi[0][1], s_qi[0][8], s_qi[0][9], cx1, cy1);
+            if (cn1) r1 = exact_corner(w10, w11, s_qi[1][0], s_qi[1][1], s_qi[1][8], s_qi[1][9], cx1, cy1);
+            if (cn2) r2 = exact_corner(w20, w21, s_qi[1][0], s_qi[1][1], s_qi[1][8], s_qi[1][9], cx1, cy1);
+            if (many) {
+                // a tile evaluated as a whole, a cluster of unsafe pixels: every lane its own samples, component by component
+#pragma unroll 1
+                for (int c = 0; c < 3; ++c) {
+                    const bool nd = c == 0 ? (need0 && !cn0) : (c == 1 ? (need1 && !cn1) : (need2 && !cn2));
+                    if (__ballot(nd) == 0) continue;
+                    int S = 128;
+                    if (nd) {
+                        const uint4* blk = COMPACT ? reinterpret_cast<const uint4*>(s_img) + ((mcu & (TILE_MCUS - 1)) * 3 + c) * 8
+                                                   : reinterpret_cast<const uint4*>(p.coef) + ((size_t)mcu * 3 + c) * 8;
+                        S = exact_sample_lane(blk, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
+                    }
+                    const float rv = (float)(S - 128);
+                    if (nd) {
+                        if (c == 0) r0 = rv;
+                        else if (c == 1) r1 = rv;
+                        else r2 = rv;
+                    }
+                }
+            } else {
+                // by the whole wavefront, one sample after the other, lane = coefficient position
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        if (g0 | g1 | g2) {   // wave-uniform
+                            uint32_t c, L;
+                            pop(g0, g1, g2, c, L);
+                            const int xL = __builtin_amdgcn_readlane((int)x, (int)L), yL = __builtin_amdgcn_readlane((int)y, (int)L);
+                            const int F = cf[k] * (int)s_qi[c ? 1 : 0][lane];          // m_8x8block after MCU.cpp:110-112
+                            const int S = exact_sample_wave(ccl * (float)F, s_cos, xL, yL, F != 0);
+                            const float rv = (float)(S - 128);
+                            if (lane == L) {
+                                if (c == 0) r0 = rv;
+                                else if (c == 1) r1 = rv;
+                                else r2 = rv;
+                            }
+                        }
+                    }
+                    if (!(g0 | g1 | g2)) break;
+                    // the next batch (clusters only)
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) {
+                        cf[k] = 0;
+                        if (a0 | a1 | a2) {
+                            uint32_t c, L;
+                            pop(a0, a1, a2, c, L);
+                            const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
+                            cf[k] = fetch_coef(mcuL, c, k);
+                        }
+                    }
+                }
+            }
+            // the tile's own stores (issued before this pass's loads) must have been performed before bytes of theirs are patched
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (valid) {
+                const uint32_t px = colour_exact((int)r0 + 128, (int)r1 + 128, (int)r2 + 128);
+                size_t off;
+                if (p.rgb_table) {
+                    const uint32_t img = trow / p.rows_per_img;
+                    off = (size_t)(reinterpret_cast<uintptr_t>(p.rgb_table[img]) - reinterpret_cast<uintptr_t>(p.rgb)) +
+                          (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch;
+                } else {
+                    off = (size_t)trow * 8 * p.pitch;
+                }
+                uint8_t* o = p.rgb + off + (size_t)x * p.pitch + (size_t)(m0 + g) * 24 + y * 3;
+                o[0] = (uint8_t)px;
+                o[1] = (uint8_t)(px >> 8);
+                o[2] = (uint8_t)(px >> 16);
+            }
+        }
+    };
+
+    // Compact stream only.  The queue entries [first, last) were pushed by the tile whose image stands in LDS; those of
+    // them with an unsafe sample in a block that is NOT corner-only get that sample evaluated now, in the reference's order,
+    // from the image (the whole wavefront per sample, lane = coefficient position; lane-parallel when there are many) and
+    // written back into the entry with its key cleared: later the compact stream offers no block to read.  What remains
+    // for the deferred pass: corner-only samples (from the stashed words), the colour conversion and the three bytes.
+    auto resolve_noncorner = [&](uint32_t first, uint32_t last) {
+        uint32_t lane = (uint32_t)tid;
+        asm volatile("" : "+v"(lane));
+        const uint32_t e = first + lane;
+        const bool valid = e < last;
+        uint32_t pos = 0;
+        float f0 = -1.0f, f1 = -1.0f, f2 = -1.0f;
+        if (valid) {
+            pos = s_queue[e * QW];
+            const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 4);
+            f0 = __uint_as_float(b.x), f1 = __uint_as_float(b.y), f2 = __uint_as_float(b.z);
+        }
+        const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
+        const bool n0 = f0 >= 0.0f && !(pos & (1u << 9)), n1 = f1 >= 0.0f && !(pos & (1u << 10)), n2 = f2 >= 0.0f && !(pos & (1u << 11));
+        unsigned long long g0 = __ballot(n0), g1 = __ballot(n1), g2 = __ballot(n2);
+        if (!(g0 | g1 | g2)) return;
+        float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+        const uint16_t* img16 = reinterpret_cast<const uint16_t*>(s_img);
+        if (__popcll(g0) + __popcll(g1) + __popcll(g2) > 6) {
+            // a cluster: every lane its own samples, component by component
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                const bool nd = c == 0 ? n0 : (c == 1 ? n1 : n2);
+                if (__ballot(nd) == 0) continue;
+                int S = 128;
+                if (nd) S = exact_sample_lane(reinterpret_cast<const uint4*>(s_img) + (g * 3 + c) * 8, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
+                const float rv = (float)(S - 128);
+                if (c == 0) r0 = rv;
+                else if (c == 1) r1 = rv;
+                else r2 = rv;
+            }
+        } else {
+            const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
+            while (g0 | g1 | g2) {   // wave-uniform
+                unsigned long long& mm = g0 ? g0 : (g1 ? g1 : g2);
+                const uint32_t c = g0 ? 0u : (g1 ? 1u : 2u);
+                const uint32_t L = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                const uint32_t gL = (uint32_t)__builtin_amdgcn_readlane((int)g, (int)L);
+                const int xL = __builtin_amdgcn_readlane((int)x, (int)L), yL = __builtin_amdgcn_readlane((int)y, (int)L);
+                const int F = (int)(int16_t)img16[(gL * 3 + c) * 64 + lane] * (int)s_qi[c ? 1 : 0][lane];   // m_8x8block after MCU.cpp:110-112
+                const int S = exact_sample_wave(ccl * (float)F, s_cos, xL, yL, F != 0);
+                const float rv = (float)(S - 128);
+                if (lane == L) {
+                    if (c == 0) r0 = rv;
+                    else if (c == 1) r1 = rv;
+                    else r2 = rv;
+                }
+            }
+        }
+        if (n0) s_queue[e * QW + 1] = __float_as_uint(r0), s_queue[e * QW + 4] = __float_as_uint(-1.0f);   // key < 0: settled
+        if (n1) s_queue[e * QW + 2] = __float_as_uint(r1), s_queue[e * QW + 5] = __float_as_uint(-1.0f);
+        if (n2) s_queue[e * QW + 3] = __float_as_uint(r2), s_queue[e * QW + 6] = __float_as_uint(-1.0f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
     bool have_prev = false;
     size_t prev_off = 0;
     uint32_t prev_nm = 0;
+    uint32_t nq = 0;           // queued positions (wave-uniform)
+    uint32_t nover = 0;        // entries of the overflow list
+    uint32_t nq_total = 0;
     // A tile's inputs: one 16-byte coefficient row of each component block and the three blocks' bounds.  They are asked
-    // for one tile ahead (a second register set), so that a wavefront's tile costs it its instructions and not a memory
-    // round trip on top -- with four or five wavefronts per SIMD the others cannot cover that wait.
+    // for one tile ahead (a second register set: the 16-wavefront workgroup leaves 128 VGPRs per lane), so that a
+    // wavefront's tile costs it its instructions and not a memory round trip on top -- with four wavefronts per SIMD the
+    // others cannot cover that wait.
     // Compact stream: the tile's records (4 bytes per non-zero AC coefficient, ~90 per tile on the 8K workload against 3 KiB of
     // dense rows), its 24 DC values and the bounds are asked for one tile ahead, the two words of the first-record table
     // two tiles ahead (they say where the records are); the blocks are rebuilt in LDS when the tile's turn comes.
@@ -744,7 +1049,7 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
     };
     auto tile_records = [&](uint32_t tk, uint32_t& rs, uint32_t& rn) {
         const uint32_t tile = wg_tile0 + tk;
-        const uint32_t a = p.mcu_start[tile * TILE_MCUS], b = p.mcu_start[tile * TILE_MCUS + TILE_MCUS];   // wave-uniform addresses: scalar loads
+        const uint32_t a = p.tile_start[tile], b = p.tile_start[tile + 1];   // wave-uniform addresses: scalar loads
         rs = a;
         rn = (b >= a && b <= p.rec_cap && b - a <= 24u * 63u) ? b - a : 0u;   // (a corrupt stream may leave anything in the table)
     };
@@ -773,7 +1078,16 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             in.dcw = l < 24u ? (uint32_t)(uint16_t)p.dc16[mcu_ld * 3 + l] : 0u;
         } else {
             const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu_ld * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
+#if defined(KPEG_ABLATE_HALFLINE)
+            // timing experiment: rows 4..7 (the second 64 bytes of every block) are not loaded -- does half a line cost half?
+            in.d0 = in.d1 = in.d2 = make_uint4(0, 0, 0, 0);
+            if (u < 4) in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+#elif defined(KPEG_ABLATE_QUARTERLINE)
+            in.d0 = in.d1 = in.d2 = make_uint4(0, 0, 0, 0);
+            if (u < 2) in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+#else
             in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
+#endif
         }
         const float* eb = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(p.ebound + mcu_ld * 3) + lane_mcu * 12u);
         in.e0 = eb[0], in.e1 = eb[1], in.e2 = eb[2];
@@ -793,9 +1107,11 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         if (tilek_next < wg_ntiles) tile_records(tilek_next, rs_next, rn_next);
     for (;;) {
         const uint32_t tilek = tilek_cur;              // this tile's number inside the workgroup's range
-        if (!(tilek < wg_ntiles)) break;               // wave-uniform
+        const bool more = tilek < wg_ntiles;           // wave-uniform
         const uint32_t tile = wg_tile0 + tilek;
-        const uint32_t tilek_after = take_tile();
+        uint32_t tilek_after = 0;
+        if (more) {
+        tilek_after = take_tile();
         if constexpr (COMPACT)
             if (tilek_after < wg_ntiles) tile_records(tilek_after, rs_after, rn_after);   // two tiles ahead: nothing waits for these
         if constexpr (!PREFETCH) issue_loads(tilek, cur, 0, 0);
@@ -835,23 +1151,22 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             if (tilek_next < wg_ntiles) issue_loads(tilek_next, nxt, rs_next, rn_next);
             asm volatile("" ::: "memory");
         }
+        // The first word of rows 0 and 1 of the MCU's three blocks (coefficients (0,0),(0,1) and (1,0),(1,1)): they sit on
+        // lanes 0 and 4 of the group.  A queued pixel takes them along, so the fix-up pass settles corner-only blocks (nine
+        // unsafe samples in ten) without touching memory.
+        constexpr bool STASH = COMPACT || KPEG_K4_STASH_DENSE;
+        const int lrow0 = tid & 56, lrow1 = lrow0 | 4;
+        uint32_t cw00 = 0, cw01 = 0, cw10 = 0, cw11 = 0, cw20 = 0, cw21 = 0;
+        if constexpr (STASH && !COMPACT) {   // (the compact path reads them from the tile's LDS image when it queues a pixel)
+            cw00 = (uint32_t)__shfl((int)d0.x, lrow0), cw01 = (uint32_t)__shfl((int)d0.x, lrow1);
+            cw10 = (uint32_t)__shfl((int)d1.x, lrow0), cw11 = (uint32_t)__shfl((int)d1.x, lrow1);
+            cw20 = (uint32_t)__shfl((int)d2.x, lrow0), cw21 = (uint32_t)__shfl((int)d2.x, lrow1);
+        }
         const size_t cur_off = tile_offset(trow, m0);
         if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
         have_prev = true;
         prev_off = cur_off;
         prev_nm = nm;
-
-        // Quantised high frequencies are mostly zero: if no block of this wavefront has a coefficient outside
-        // its top-left 6x6 (luma) / 4x4 (chroma) corner, the terms of the empty rows and columns are left out
-        // (same floats as the full transform, see row_idct8).  8K q75: luma 6x6 for 98 % of the tiles, chroma 4x4 for 99 %.
-        // All four wave-uniform conditions of a tile are taken together, ahead of the first branch on any of them: a scalar
-        // branch on a vector compare stalls the wavefront until the compare has left the vector pipe, once instead of four times.
-        const bool big0 = __ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0) != 0;
-        const bool big1 = __ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0) != 0;
-        const bool big2 = __ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0) != 0;
-        // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
-        const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
-        const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
 
         float v[3][8];
 #ifdef KPEG_ABLATE_IDCT
@@ -860,27 +1175,55 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             v[1][i] = __uint_as_float(d1.y + i) * 1e-30f;
             v[2][i] = __uint_as_float(d2.z + i) * 1e-30f;
         }
-        (void)big0, (void)big1, (void)big2;
 #else
-        if (big0) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        // Quantised high frequencies are mostly zero: if no block of this wavefront has a coefficient outside
+        // its top-left 6x6 (luma) / 4x4 (chroma) corner, the terms of the empty rows and columns are left out
+        // (same floats as the full transform, see row_idct8).  8K q75: luma 6x6 for 98 % of the tiles, chroma 4x4 for 99 %.
+#if KPEG_K4_LUMA4
+        // (a third luma size: 4x4 -- what smooth content quantises to)
+        if (__ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0)) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        else if (__ballot((d0.z | (u >= 4 ? (d0.x | d0.y) : 0u)) != 0)) block_fast<6>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        else block_fast<4>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+#else
+        if (__ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0)) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
         else block_fast<6>(d0, lc, &s_m[0][u * 8], 0, v[0]);
-        if (big1) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+#endif
+#if KPEG_K4_CHROMA2
+        // chroma blocks of smooth content rarely have anything outside their 2x2 corner (DC and the two first-order terms)
+        if (__ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0)) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        else if (__ballot((d1.y | (u >= 2 ? d1.x : 0u)) != 0)) block_fast<4>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        else block_fast<2>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        else if (__ballot((d2.y | (u >= 2 ? d2.x : 0u)) != 0)) block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        else block_fast<2>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+#else
+        if (__ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0)) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
         else block_fast<4>(d1, lc, &s_m[1][u * 8], 1, v[1]);
-        if (big2) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
         else block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+#endif
 #endif
         // |fast - rint(fast)| + nthr >= 0  <=>  within the block's bound of a rounding boundary
         const float nthr0 = fabsf(e0) - 0.5f, nthr1 = fabsf(e1) - 0.5f, nthr2 = fabsf(e2) - 0.5f;
+        // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
+        const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
+        const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
 
-        // Level shift + colour for the 8 pixels of this lane's row.  Per pixel the sign of one word says whether the
-        // reference-order evaluation is needed (sign clear): a fast value within its block's bound of a rounding boundary,
-        // or a G term too close to an integer for the f32 arithmetic.  Nearly every wavefront has a few such pixels (true
-        // ties are structural: equal and opposite (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5
-        // exactly); their signs are shifted into `ub`, one bit per pixel column.
+        // Level shift + colour for the 8 pixels of this lane's row.  Per pixel one float key says
+        // whether the reference-order evaluation is needed (key >= 0): a fast value within its block's
+        // bound of a rounding boundary, or a G term too close to an integer for the f32 arithmetic.
+        // Nearly every wavefront has a few such pixels (true ties are structural: equal and opposite
+        // (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5 exactly): their positions are
+        // queued straight from this loop with ballot compaction (no atomics, no second pass).
         uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
-        uint32_t ubY = 0, ubB = 0, ubR = 0, ubG = 0;   // per component and for the G term: bit 7 - i = pixel column i is safe
-        uint32_t hp[3][4];                              // the rounded samples as f16 pairs
-        float py = 0.0f, pb = 0.0f, pr = 0.0f;          // the even column's, until its odd neighbour's are there
+        const uint32_t nq_tile = nq;
+        const uint32_t pos_lane = (uint32_t)grp | ((uint32_t)lane8 << 3) | (tilek << 12) | ((__float_as_uint(e0) >> 31) << 9) |
+                                  ((__float_as_uint(e1) >> 31) << 10) | ((__float_as_uint(e2) >> 31) << 11);
+        const unsigned long long active_mask = __ballot(active);
+        bool pushed_nc = false;   // compact stream: this tile queued a pixel with an unsafe sample in a block that is not corner-only
+        uint32_t nc_lane = 0;
+        constexpr int PG = COMPACT ? KPEG_PUSH_GROUP_COMPACT : KPEG_PUSH_GROUP;   // pixel columns per unsafe-pixel test
+        uint32_t gsafe = 0x80000000u, sf[PG];
         // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
         auto pixel_loop = [&](auto with_wide) {
 #pragma unroll
@@ -920,31 +1263,74 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
                         kg = 0x80000000u;   // G is exact here
                     }
                 }
+                const uint32_t safe = __float_as_uint(fy) & __float_as_uint(fb) & __float_as_uint(fr) & kg;
                 pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
                 pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
                 pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
-#if defined(KPEG_ABLATE_PUSH)
-                (void)fy, (void)fb, (void)fr, (void)kg;   // timing experiment: no unsafe-pixel arithmetic survives
-#else
-                // the signs into the four bytes: u << 1 | sign (one v_alignbit each, in place of the ANDs that used to merge them)
-                ubY = __builtin_amdgcn_alignbit(ubY, __float_as_uint(fy), 31);
-                ubB = __builtin_amdgcn_alignbit(ubB, __float_as_uint(fb), 31);
-                ubR = __builtin_amdgcn_alignbit(ubR, __float_as_uint(fr), 31);
-                ubG = __builtin_amdgcn_alignbit(ubG, kg, 31);
-                if (i & 1) {
-                    // two columns' rounded samples as an f16 pair (exact: integers, |.| <= 2048 wherever the bound is finite enough to matter;
-                    // k_fixup treats a larger one as unsafe)
-                    hp[0][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(py, ry));
-                    hp[1][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pb, rb));
-                    hp[2][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pr, rr));
-                } else {
-                    py = ry, pb = rb, pr = rr;
+#if defined(KPEG_ABLATE_PUSH_KEEPSAFE)
+                // timing experiment: the safety arithmetic stays (kept alive), no test, no queue
+                asm volatile("" ::"v"(safe));
+#elif !defined(KPEG_ABLATE_PUSH)
+                // A scalar branch on a vector compare costs a wavefront ~175 cycles (the VALU result has to reach the scalar
+                // unit): one test per pixel column -- eight per tile, plus one more in every taken branch -- was 13 us of the
+                // kernel (profiles/r02: ablations).  So: one test per GROUP of KPEG_PUSH_GROUP columns; a group with an unsafe
+                // pixel (2.5 pixels per tile on the 8K workload) takes its ballots together and queues its pixels with
+                // ballot compaction (no atomics).
+                sf[i % PG] = safe;
+                gsafe &= safe;
+                if ((i % PG) == PG - 1) {
+                    if (__ballot((int)gsafe >= 0) & active_mask) {
+                        unsigned long long gb[PG];
+#pragma unroll
+                        for (int j = 0; j < PG; ++j) gb[j] = __ballot((int)sf[j] >= 0) & active_mask;
+                        uint32_t base_slot = nq;
+#pragma unroll
+                        for (int j = 0; j < PG; ++j) {
+                            const int ii = i - (PG - 1) + j;
+                            const unsigned long long bal = gb[j];
+                            const uint32_t slot = base_slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
+#ifdef KPEG_ABLATE_PUSHBODY
+                            if (slot == 0xFFFFFFFFu)   // timing experiment: the tests and the count stay, the entry is never written
+#endif
+                            if ((int)sf[j] >= 0 && active) {
+                                // the pixel's rounded samples and keys again, from the fast values (cheaper than keeping them)
+                                const float wy = v[0][ii], wb = v[1][ii], wr = v[2][ii];
+                                const float qy = __builtin_rintf(wy), qb = __builtin_rintf(wb), qr = __builtin_rintf(wr);
+                                const float gy = fabsf(wy - qy) + nthr0, gbk = fabsf(wb - qb) + nthr1, gr = fabsf(wr - qr) + nthr2;
+                                const uint32_t pw = pos_lane | ((uint32_t)ii << 6);
+                                if (slot < QUEUE_CAP) {
+                                    uint32_t* q = s_queue + slot * QW;
+                                    q[0] = pw;
+                                    q[1] = __float_as_uint(qy), q[2] = __float_as_uint(qb), q[3] = __float_as_uint(qr);
+                                    q[4] = __float_as_uint(gy), q[5] = __float_as_uint(gbk), q[6] = __float_as_uint(gr);
+                                    // the 2x2 corner of the pixel's three blocks (rows 0 and 1, columns 0 and 1)
+                                    if constexpr (COMPACT) {
+                                        const uint32_t* im = s_img + (grp * 3) * 32;   // block c at + 32 c words: rows 0 and 1 at words 0 and 4
+                                        q[8] = im[0], q[9] = im[4], q[10] = im[32], q[11] = im[36], q[12] = im[64], q[13] = im[68];
+                                    } else if constexpr (STASH) {
+                                        q[8] = cw00, q[9] = cw01, q[10] = cw10, q[11] = cw11, q[12] = cw20, q[13] = cw21;
+                                    }
+                                } else {
+                                    s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
+                                }
+                                if constexpr (COMPACT)
+                                    nc_lane |= (~__float_as_uint(gy) & ~__float_as_uint(e0)) | (~__float_as_uint(gbk) & ~__float_as_uint(e1)) |
+                                               (~__float_as_uint(gr) & ~__float_as_uint(e2));   // sign set: unsafe (key >= 0) in a block whose bound is positive (not corner-only)
+                            }
+                            base_slot += __popcll(bal);
+                        }
+                        nq = base_slot;
+                    }
+                    gsafe = 0x80000000u;
                 }
+#else
+                (void)safe;
 #endif
             }
         };
         if (any_wide) pixel_loop(std::true_type{});
         else pixel_loop(std::false_type{});
+        if constexpr (COMPACT) pushed_nc = __ballot((int)nc_lane < 0) != 0;
         {
             // 24 bytes of pixel row lane8, MCU grp (groups beyond nm write garbage that is never stored)
             uint2* dst = reinterpret_cast<uint2*>(s_tile + lane8 * TILE_ROW_STRIDE + grp * 24);
@@ -952,32 +1338,44 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             dst[1] = make_uint2(pk[2], pk[3]);
             dst[2] = make_uint2(pk[4], pk[5]);
         }
-#if !defined(KPEG_ABLATE_PUSH)
-        {
-            // this lane's byte of the tile's unsafe-pixel mask: bit 7 - i = pixel column i needs the reference-order evaluation
-            uint32_t lane_off = (uint32_t)tid;
-            asm volatile("" : "+v"(lane_off));
-            const uint32_t marked = active ? ~(ubY & ubB & ubR & ubG) & 0xFFu : 0u;
-            p.umask[(size_t)tile * UMASK_TILE_BYTES + lane_off] = (uint8_t)marked;
-            if (marked) {
-                // ... and what k_fixup needs to settle them: the row's rounded samples and the four bytes (stores under the lanes' own
-                // condition: no test the wavefront waits for)
-                uint4v* row = reinterpret_cast<uint4v*>(p.urows + ((size_t)tile * 64 + lane_off) * UROW_BYTES);
-                const uint4v h0 = {hp[0][0], hp[0][1], hp[0][2], hp[0][3]}, h1 = {hp[1][0], hp[1][1], hp[1][2], hp[1][3]}, h2 = {hp[2][0], hp[2][1], hp[2][2], hp[2][3]};
-                row[0] = h0, row[1] = h1, row[2] = h2;
-                reinterpret_cast<uint32_t*>(row)[12] = (ubY & 0xFFu) | ((ubB & 0xFFu) << 8) | ((ubR & 0xFFu) << 16) | (ubG << 24);
-            }
+        nq_total += nq - nq_tile;
+        if (nq > QUEUE_CAP) {   // the rest went to the overflow list
+            nover = nq - QUEUE_CAP;
+            nq = QUEUE_CAP;
         }
+        if constexpr (COMPACT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#ifndef KPEG_ABLATE_RESOLVE
+            if (pushed_nc) resolve_noncorner(min(nq_tile, (uint32_t)QUEUE_CAP), nq);   // while this tile's image stands
 #endif
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the next iteration writes this tile back before its own colour phase overwrites the LDS tile
+        }
+        // Fix-ups are due: a pass's worth of queued pixels or the end of this wavefront's tiles.  Few
+        // values of the tile loop are live here.  Every tile a queued position refers to must have been stored before
+        // (run_fixups waits for the stores to be performed before it patches bytes of theirs).
+        if (nq >= QUEUE_FLUSH || (!more && nq)) {   // wave-uniform
+            if (have_prev) write_back(prev_off, prev_nm);
+            have_prev = false;
+            if (!p.skip_exact) run_fixups(nq, nover, tilek);
+            nq = 0;
+            nover = 0;
+        }
+        if (!more) break;
         if constexpr (PREFETCH) cur = nxt;
         tilek_cur = tilek_next;
         tilek_next = tilek_after;
         rs_next = rs_after, rn_next = rn_after;
     }
     if (have_prev) write_back(prev_off, prev_nm);
+#if defined(KPEG_COUNT_COOP) || defined(KPEG_COUNT_MANY) || defined(KPEG_COUNT_FLUSH) || defined(KPEG_COUNT_CORNER)
+    nq_total = dbg_count;
+#else
+    (void)dbg_count;
+#endif
 #ifdef KPEG_K4_STAMP
     if (tid == 0) {
         const unsigned long long dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
@@ -987,466 +1385,24 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             g_k4_stamp[w * 4 + 0] = stamp_r0;
             g_k4_stamp[w * 4 + 1] = stamp_r0 + dr;
             g_k4_stamp[w * 4 + 2] = dc;
-            // XCC_ID [35:32] | HW_ID [31:0] (wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
-            g_k4_stamp[w * 4 + 3] = ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 32) |
+            // unsafe pixels [63:48] | XCC_ID [35:32] | HW_ID [31:0] (wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+            g_k4_stamp[w * 4 + 3] = ((unsigned long long)(nq_total & 0xFFFFu) << 48) |
+                                    ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 32) |
                                     __builtin_amdgcn_s_getreg(4 | (31 << 11));
         }
     }
 #endif
-}
-
-// inclusive prefix maximum over the wavefront (unsigned; lanes a DPP control does not write read 0, the identity here)
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
-{
-    uint32_t s = x;
-    s = max(s, (uint32_t)dpp0<0x111>((int)x));               // row_shr:1
-    s = max(s, (uint32_t)dpp0<0x112>((int)x));               // row_shr:2
-    s = max(s, (uint32_t)dpp0<0x113>((int)x));               // row_shr:3
-    s = max(s, (uint32_t)dpp0<0x114, 0xF, 0xE>((int)s));     // row_shr:4 into lanes 4..15 of the rows
-    s = max(s, (uint32_t)dpp0<0x118, 0xF, 0xC>((int)s));     // row_shr:8 into lanes 8..15
-    s = max(s, (uint32_t)dpp0<0x142, 0xA, 0xF>((int)s));     // row_bcast:15
-    s = max(s, (uint32_t)dpp0<0x143, 0xC, 0xF>((int)s));     // row_bcast:31
-    return s;
-}
-
-// ---- k_fixup: the marked pixels, in the reference's own order ---------------------------------------------------
-// K4 leaves one byte per lane and tile in the unsafe-pixel mask (bit 7 - i = pixel column i of pixel row `lane & 7` of MCU
-// `lane >> 3` of the tile) and, for the rows that have a marked pixel, the row's rounded fast samples with the components it
-// vouches for (UROW_BYTES).  Here a wavefront takes chunks of FX_CHUNK_TILES tiles of the mask, lists their marked pixels in
-// LDS (popcount + wavefront scan: no atomics; what does not fill a batch of 64 waits for the next chunk) and settles them one
-// lane per pixel: the components K4 does not vouch for are evaluated as MCU::computeIDCT has them (MCU.cpp:184-198: float
-// accumulator, double products, u outer, v inner, zero terms leave the accumulator as it is), the others keep K4's rounded
-// value, then performLevelShift and convertYCbCrToRGB (colour_exact) and the pixel's three bytes stored over what K4 wrote.
-//   corner-only blocks (the sign of the block's bound; nine in ten: ties of chroma blocks, equal and opposite (0,1)/(1,0) terms
-//     that cancel on the diagonal): four terms by the lane itself -- dense layout from the block's first two rows, compact
-//     stream from the MCU's first four (luma) or last seven (chroma) records, which hold a block of at most three whole;
-//   any other block: dense layout, as it stands in natural order (exact_sample_lane); compact stream, by its lane too -- the
-//     positions of the block's records in a 64-bit mask, the values stored in LDS at the rank of their position (= natural
-//     order), the mask walked -- and blocks with more than FX_SLOTS records by the whole wavefront (exact_sample_wave), one
-//     sample after the other.
-// (A version that took nothing but positions from K4 and evaluated all three components of every marked pixel -- an order-free
-// double sum first, the reference's order only where that sum lay within the block's bound of a rounding boundary -- was
-// bit-exact too and took 20 us: 96 % of the marked pixels are chroma ties whose luma block has most of the MCU's records.)
-// The call's last kernel: its last wavefront hands the status words to the host mirror (status_epilogue).
-#ifndef KPEG_FX_WAVES
-#define KPEG_FX_WAVES 16
-#endif
-constexpr int FX_WAVES = KPEG_FX_WAVES, FX_THREADS = 64 * FX_WAVES;
-constexpr int FX_CHUNK_TILES = 8;    // tiles per chunk of the mask: 512 bytes, eight bytes per lane
-constexpr int FX_LIST = 448;         // marked pixels listed at a time (+ up to 63 left over from the chunk before)
-constexpr int FX_SLOTS = 24;         // records of one block kept per lane for the walk in natural order
-
-#ifdef KPEG_FX_STAMP
-__device__ unsigned long long g_fx_stamp[8192 * 16];   // diagnostic build only (tools/fx_clock.py): per wavefront, shader cycles spent per phase
-#define FX_T(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); fx_acc[k] += _t - fx_last; fx_last = _t; } while (0)
-#else
-#define FX_T(k) do { } while (0)
-#endif
-template <bool COMPACT>
-__global__ __launch_bounds__(FX_THREADS) void k_fixup(IdctParams p, QTables qt)
-{
-#ifdef KPEG_FX_STAMP
-    unsigned long long fx_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fx_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long fx_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    __shared__ uint32_t s_list_all[FX_WAVES][FX_LIST + 64];
-    __shared__ int16_t s_val_all[COMPACT ? FX_WAVES : 1][FX_SLOTS * 64];
-    __shared__ __attribute__((aligned(16))) uint32_t s_coop_all[COMPACT ? FX_WAVES : 1][32];   // one block, int16, natural order
-    __shared__ __attribute__((aligned(16))) uint32_t s_qi[2][64];   // quantisers, natural order
-    __shared__ __attribute__((aligned(8))) uint2 s_qc[2][64];       // .x the quantiser, .y (bits) cc = Cf[u] * Cf[v] in float (MCU.cpp:189-192): one read per record
-    __shared__ double s_cos[64];
-    __shared__ uint32_t s_wg[2];      // [0] wavefronts of this workgroup that are done, [1] pixels they settled
-    __shared__ uint32_t s_take;       // chunks of this workgroup handed out so far
-
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t* const s_list = s_list_all[wave];
-    int16_t* const s_val = s_val_all[COMPACT ? wave : 0];
-    uint32_t* const s_coop = s_coop_all[COMPACT ? wave : 0];
-    const uint32_t nchunks = (p.ntiles + FX_CHUNK_TILES - 1) / FX_CHUNK_TILES;
-    // A chunk's mask, one byte of every tile per lane: lane l gets byte l (= lane l of K4's wavefront) of each of the chunk's tiles, so
-    // that the eight bytes of an MCU -- marked pixels come in clusters, a block's whole diagonal and more -- lie on eight lanes.
-    // Word w of the result: the bytes of tiles 4 w .. 4 w + 3.
-    constexpr int MW = FX_CHUNK_TILES / 4;
-    struct Mask { uint32_t w[MW]; };
-    auto load_mask = [&](uint32_t chunk) -> Mask {
-        Mask m;
-        uint32_t by[FX_CHUNK_TILES];
-        // (the loads in flight together: the addresses are clamped into the mask and what lies outside is dropped afterwards --
-        // a load under a condition each would be as many round trips one after the other)
-        const uint32_t tile0 = min(chunk, nchunks - 1) * FX_CHUNK_TILES;
-        uint32_t l = lane;
-        asm volatile("" : "+v"(l));
-#pragma unroll
-        for (int k = 0; k < FX_CHUNK_TILES; ++k) by[k] = (uint32_t)p.umask[(size_t)min(tile0 + (uint32_t)k, p.ntiles - 1) * UMASK_TILE_BYTES + l];
-#pragma unroll
-        for (int k = 0; k < FX_CHUNK_TILES; ++k) by[k] = (chunk < nchunks && tile0 + (uint32_t)k < p.ntiles) ? by[k] : 0u;   // (wave-uniform conditions)
-#pragma unroll
-        for (int w = 0; w < MW; ++w) m.w[w] = by[4 * w] | (by[4 * w + 1] << 8) | (by[4 * w + 2] << 16) | (by[4 * w + 3] << 24);
-        return m;
-    };
-    // Workgroup b owns chunks b, b + gridDim.x, ... (neighbouring chunks, alike in what they hold, go to different workgroups).  Its
-    // wavefronts start with one each and take the others through a counter in LDS as they go: chunks differ by an order of
-    // magnitude in what they hold, and a wavefront that drew a heavy one simply takes fewer.  (One counter for the whole launch
-    // was measured: 4000 device-scope atomics on 32 words take 25 us.)
-    auto take_chunk = [&]() -> uint32_t {
-        uint32_t k = 0;
-        if (lane == 0) k = atomicAdd(&s_take, 1u);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-        return k < 0x10000u ? blockIdx.x + k * gridDim.x : 0xFFFFFFFFu;
-    };
-    uint32_t chunk = blockIdx.x + wave * gridDim.x;
-    Mask m_next = load_mask(chunk);   // (on its way while the tables are set up)
-    if (threadIdx.x < 128) {
-        const uint32_t t = threadIdx.x >> 6, k = threadIdx.x & 63;
-        s_qi[t][k] = qt.q[t][k];
-        s_qc[t][k] = make_uint2((uint32_t)qt.q[t][k], __float_as_uint(cc_of((int)(k >> 3), (int)(k & 7))));
-    } else if (threadIdx.x < 192) {
-        s_cos[lane] = c_cos[lane];
-    } else if (threadIdx.x == 192) {
-        s_wg[0] = 0;
-        s_wg[1] = 0;
-        s_take = FX_WAVES;   // (the first FX_WAVES are the wavefronts' own)
-    }
-    __syncthreads();
-    FX_T(0);   // set-up
-    const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
-    const float c0 = 0x1.6a09e6p-1f;
-    uint32_t settled = 0;   // (wave-uniform)
-    uint32_t nl = 0;        // entries in the list (wave-uniform)
-    // One batch: list entries [first, first + 64), those below `end` valid.  entry = tile << 9 | lane of the tile << 3 | bit of its byte
-    auto process = [&](uint32_t first, uint32_t end) {
-        const bool valid = first + lane < end;
-        const uint32_t ent = valid ? s_list[first + lane] : 0u;
-        const uint32_t tile = min(ent >> 9, p.ntiles - 1);
-        const uint32_t Lt = (ent >> 3) & 63u;                                           // lane of K4's wavefront: MCU of the tile << 3 | pixel row
-        const uint32_t g = Lt >> 3, x = Lt & 7u, y = 7u - (ent & 7u);                   // MCU, pixel row, pixel column
-        const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
-        const uint32_t m0 = tcol * TILE_MCUS;
-        const size_t mcu = (size_t)trow * p.mcus_w + m0 + g;
-        // What K4 left for the pixel's row: the rounded fast samples and, per component, whether it vouches for them.  A sample beyond
-        // what f16 holds exactly counts as not vouched for.
-        int S0 = 128, S1 = 128, S2 = 128;   // the three samples after the level shift
-        uint32_t need = 0;                  // bit c: component c is to be evaluated in the reference's order
-        float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
-        if (valid) {
-            const uint8_t* row = p.urows + ((size_t)tile * 64 + Lt) * UROW_BYTES;
-            const uint32_t keys = reinterpret_cast<const uint32_t*>(row)[12];
-            const _Float16* h = reinterpret_cast<const _Float16*>(row);
-            const float f0 = (float)h[y], f1 = (float)h[8 + y], f2 = (float)h[16 + y];
-            S0 = (int)f0 + 128, S1 = (int)f1 + 128, S2 = (int)f2 + 128;
-            const uint32_t sh = 7u - y;
-            need = (((keys >> sh) & 1u) && fabsf(f0) < 2047.0f ? 0u : 1u) | (((keys >> (8 + sh)) & 1u) && fabsf(f1) < 2047.0f ? 0u : 2u) |
-                   (((keys >> (16 + sh)) & 1u) && fabsf(f2) < 2047.0f ? 0u : 4u);
-            struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };   // (one 12-byte load)
-            const F3 eb = *reinterpret_cast<const F3*>(p.ebound + mcu * 3);
-            e0 = eb.a, e1 = eb.b, e2 = eb.c;   // (their signs: the block is corner-only)
-        }
-        const double* const cx = s_cos + x * 8, * const cy = s_cos + y * 8;
-        // MCU::computeIDCT's sum (MCU.cpp:184-198) for a block that has nothing outside (0,0), (0,1), (1,0), (1,1), in its order; a zero
-        // term leaves the float accumulator as it is (x + (+-0) == x), so none needs a test.  cos((2x+1) 0 pi/16) == 1.0 exactly.
-        auto corner = [&](int dc, int v01, int v10, int v11, const uint32_t* qi) -> int {
-            const float fc00 = (c0 * c0) * (float)(dc * (int)qi[0]), fc01 = (c0 * 1.0f) * (float)(v01 * (int)qi[1]),
-                        fc10 = (1.0f * c0) * (float)(v10 * (int)qi[8]), fc11 = (float)(v11 * (int)qi[9]);
-            float sum = fc00;
-            sum = (float)((double)sum + (double)fc01 * cy[1]);
-            sum = (float)((double)sum + (double)fc10 * cx[1]);
-            sum = (float)((double)sum + ((double)fc11 * cx[1]) * cy[1]);
-            return level_shift((float)(0.25 * (double)sum));
-        };
-        if constexpr (!COMPACT) {
-            if (need) {
-                const uint32_t* c32 = reinterpret_cast<const uint32_t*>(p.coef) + mcu * 96;   // block c at + 32 c words: rows 0 and 1 at words 0 and 4
-                const uint4* blk = reinterpret_cast<const uint4*>(p.coef) + mcu * 3 * 8;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (!(need & (1u << c))) continue;
-                    const float e = c == 0 ? e0 : (c == 1 ? e1 : e2);
-                    int S;
-                    if (__float_as_int(e) < 0) {
-                        const uint32_t w0 = c32[c * 32], w1 = c32[c * 32 + 4];
-                        S = corner((int)(short)(w0 & 0xFFFF), (int)w0 >> 16, (int)(short)(w1 & 0xFFFF), (int)w1 >> 16, s_qi[c ? 1 : 0]);
-                    } else {
-                        S = exact_sample_lane(blk + c * 8, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
-                    }
-                    if (c == 0) S0 = S;
-                    else if (c == 1) S1 = S;
-                    else S2 = S;
-                }
-            }
-            FX_T(3);
-        } else {
-            // The MCU's records: [rs, rs + nr), block after block, zig-zag order inside a block (K2 notes every MCU's first one).
-            // Every load of this lane goes to an address of its own -- sixty-four cache lines per load instruction, which is what this
-            // kernel's time is made of -- so what lies together is loaded together: 2, 3 or 4 words per load.
-            struct __attribute__((packed, aligned(4))) U2 { uint32_t a, b; };
-            struct __attribute__((packed, aligned(4))) U4 { uint32_t a, b, c, d; };
-            uint32_t rs = 0, nr = 0;
-            int dc0 = 0, dc1 = 0, dc2 = 0;
-            const uint32_t g3 = g * 3u;
-            const uint2* const qc = &s_qc[0][0];
-            if (need) {
-                const U2 ab = *reinterpret_cast<const U2*>(p.mcu_start + mcu);
-                nr = (ab.b >= ab.a && ab.b <= p.rec_cap && ab.b - ab.a <= 3u * 63u) ? ab.b - ab.a : 0u;   // (a corrupt stream may leave anything in the table)
-                rs = nr ? ab.a : 0u;
-                {
-                    // the three DC values: six bytes, inside the eight from the word they begin in
-                    const uintptr_t da = reinterpret_cast<uintptr_t>(p.dc16 + mcu * 3);
-                    const U2 dw = *reinterpret_cast<const U2*>(da & ~(uintptr_t)3);
-                    const unsigned long long dv = (((unsigned long long)dw.b << 32) | dw.a) >> ((da & 2u) * 8u);
-                    dc0 = (int)(short)(dv & 0xFFFF), dc1 = (int)(short)((dv >> 16) & 0xFFFF), dc2 = (int)(short)((dv >> 32) & 0xFFFF);
-                }
-                const uint32_t* rp = p.rec + rs;
-                // Corner-only blocks (nine in ten of what gets here: ties of chroma blocks) have at most three records: the luma block's are
-                // the MCU's first, the chroma blocks' its last.  The first four and the last eight records say how many each block has as
-                // long as that is few, and hold them.
-                uint32_t hd[4], tl[8];
-                {
-                    const U4 h = *reinterpret_cast<const U4*>(rp);
-                    hd[0] = 0 < nr ? h.a : 31u, hd[1] = 1 < nr ? h.b : 31u, hd[2] = 2 < nr ? h.c : 31u, hd[3] = 3 < nr ? h.d : 31u;   // (block 31 does not exist)
-                    const uint32_t e8 = rs + nr >= 8u ? rs + nr - 8u : 0u;   // first of the eight
-                    const U4 ta = *reinterpret_cast<const U4*>(p.rec + e8), tb = *reinterpret_cast<const U4*>(p.rec + e8 + 4);
-                    const uint32_t tw[8] = {ta.a, ta.b, ta.c, ta.d, tb.a, tb.b, tb.c, tb.d};
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) tl[k] = (e8 + k >= rs && e8 + k < rs + nr) ? tw[k] : 31u;
-                }
-                // the luma block has fewer than four records if one of the first four is not its own
-                uint32_t lead = 0;
-                bool run = true;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    run = run && (hd[k] & 31u) == g3;
-                    lead += run ? 1u : 0u;
-                }
-                // the chroma blocks' records, counted among the last eight: all of them are there if a luma record (or no record at all) is
-                // among the eight too -- the records come block after block
-                uint32_t k2 = 0, k1 = 0, k0 = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) {
-                    const uint32_t c = (tl[k] & 31u) - g3;
-                    k2 += c == 2u ? 1u : 0u;
-                    k1 += c == 1u ? 1u : 0u;
-                    k0 += (c == 0u || (tl[k] & 31u) == 31u) ? 1u : 0u;
-                }
-                const bool tail_known = k0 != 0;
-                auto pick = [&](const uint32_t* r, int n, uint32_t c, int& v01, int& v10, int& v11) {
-                    v01 = v10 = v11 = 0;
-                    for (int k = 0; k < n; ++k) {
-                        const uint32_t pos = (r[k] >> 8) & 63u;
-                        const int val = (int)r[k] >> 16;
-                        const bool mine = (r[k] & 31u) - g3 == c;
-                        v01 = mine && pos == 1 ? val : v01;
-                        v10 = mine && pos == 8 ? val : v10;
-                        v11 = mine && pos == 9 ? val : v11;
-                    }
-                };
-                int v01, v10, v11;
-                if ((need & 1u) && __float_as_int(e0) < 0 && lead <= 3) {
-                    pick(hd, 4, 0u, v01, v10, v11);
-                    S0 = corner(dc0, v01, v10, v11, s_qi[0]);
-                    need &= ~1u;
-                }
-                if ((need & 2u) && __float_as_int(e1) < 0 && tail_known && k1 <= 3) {
-                    pick(tl, 8, 1u, v01, v10, v11);
-                    S1 = corner(dc1, v01, v10, v11, s_qi[1]);
-                    need &= ~2u;
-                }
-                if ((need & 4u) && __float_as_int(e2) < 0 && tail_known && k2 <= 3) {
-                    pick(tl, 8, 2u, v01, v10, v11);
-                    S2 = corner(dc2, v01, v10, v11, s_qi[1]);
-                    need &= ~4u;
-                }
-            }
-            FX_T(3);   // the row K4 left, index, DC values, bounds, corner-only blocks
-            // Any other block, by its lane: the positions of the block's records in a 64-bit mask, the values stored in LDS at the rank of
-            // their position (= natural order), the mask walked.  Every lane takes the first component it still has to settle; rounds
-            // until none has one.
-            uint32_t coop = 0;   // bit c: more records than a lane keeps -- by the whole wavefront below
-            while (__ballot(need != 0)) {   // wave-uniform
-                if (need) {
-                    const uint32_t c = need & 1u ? 0u : (need & 2u ? 1u : 2u);
-                    need &= ~(1u << c);
-                    const uint32_t* rp = p.rec + rs;
-                    unsigned long long mk = 0;
-                    for (uint32_t j0 = 0; j0 < nr; j0 += 4) {   // (the words behind the MCU's last record belong to the buffer: its slack)
-                        const U4 q4 = *reinterpret_cast<const U4*>(rp + j0);
-                        const uint32_t r[4] = {q4.a, q4.b, q4.c, q4.d};
-#pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
-                            const uint32_t pos = (r[k] >> 8) & 63u;
-                            mk |= (j0 + k < nr && (r[k] & 31u) - g3 == c && pos) ? 1ull << pos : 0ull;
-                        }
-                    }
-                    if ((uint32_t)__popcll(mk) > (uint32_t)FX_SLOTS) {
-                        coop |= 1u << c;
-                    } else {
-                        for (uint32_t j0 = 0; j0 < nr; j0 += 4) {
-                            const U4 q4 = *reinterpret_cast<const U4*>(rp + j0);
-                            const uint32_t r[4] = {q4.a, q4.b, q4.c, q4.d};
-#pragma unroll
-                            for (uint32_t k = 0; k < 4; ++k) {
-                                const uint32_t pos = (r[k] >> 8) & 63u;
-                                const uint32_t rank = (uint32_t)__popcll(mk & ((1ull << pos) - 1ull));
-                                if (j0 + k < nr && (r[k] & 31u) - g3 == c && pos) s_val[rank * 64u + lane] = (int16_t)((int)r[k] >> 16);   // (rank < FX_SLOTS)
-                            }
-                        }
-                        const uint2* const q1 = qc + (c ? 64 : 0);
-                        const int dc = c == 0 ? dc0 : (c == 1 ? dc1 : dc2);
-                        float sum = (c0 * c0) * (float)(dc * (int)q1[0].x);   // (0,0): both cosines 1.0, the accumulator's first value
-                        uint32_t sl = 0;
-                        while (mk) {
-                            const uint32_t pos = (uint32_t)__builtin_ctzll(mk);
-                            mk &= mk - 1;
-                            const uint2 q = q1[pos];
-                            const int F = (int)s_val[sl * 64u + lane] * (int)q.x;       // m_8x8block after MCU.cpp:110-112
-                            sl++;
-                            const float fc = __uint_as_float(q.y) * (float)F;           // cc * (float)F
-                            const double t = ((double)fc * cx[pos >> 3]) * cy[pos & 7u];
-                            sum = (float)((double)sum + t);                             // the float accumulator (MCU.cpp:195)
-                        }
-                        const int S = level_shift((float)(0.25 * (double)sum));
-                        S0 = c == 0 ? S : S0;
-                        S1 = c == 1 ? S : S1;
-                        S2 = c == 2 ? S : S2;
-                    }
-                }
-            }
-            FX_T(4);   // blocks walked in natural order by their lane
-            // Blocks with more records than that: one sample after the other, by the whole wavefront, lane = coefficient position
-            unsigned long long w0 = __ballot((coop & 1u) != 0), w1 = __ballot((coop & 2u) != 0), w2 = __ballot((coop & 4u) != 0);
-            while (w0 | w1 | w2) {   // wave-uniform
-                unsigned long long& mm = w0 ? w0 : (w1 ? w1 : w2);
-                const uint32_t c = w0 ? 0u : (w1 ? 1u : 2u);
-                const int L = __builtin_ctzll(mm);
-                mm &= mm - 1;
-                const uint32_t nrL = (uint32_t)__builtin_amdgcn_readlane((int)nr, L), r0L = (uint32_t)__builtin_amdgcn_readlane((int)rs, L);
-                const uint32_t g3L = (uint32_t)__builtin_amdgcn_readlane((int)g3, L);
-                const int xL = __builtin_amdgcn_readlane((int)x, L), yL = __builtin_amdgcn_readlane((int)y, L);
-                const int dcL = __builtin_amdgcn_readlane(c == 0 ? dc0 : (c == 1 ? dc1 : dc2), L);
-                int16_t* img16 = reinterpret_cast<int16_t*>(s_coop);
-                img16[lane] = (int16_t)(lane == 0 ? dcL : 0);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t j = lane; j < nrL; j += 64) {   // the MCU's records: this block's to their positions
-                    const uint32_t r = p.rec[r0L + j];
-                    const uint32_t pos = (r >> 8) & 63u;
-                    if ((r & 31u) - g3L == c && pos) img16[pos] = (int16_t)((int)r >> 16);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const int F = (int)img16[lane] * (int)s_qi[c ? 1 : 0][lane];   // m_8x8block after MCU.cpp:110-112
-                const int S = exact_sample_wave(ccl * (float)F, s_cos, xL, yL, F != 0);
-                if ((int)lane == L) {
-                    if (c == 0) S0 = S;
-                    else if (c == 1) S1 = S;
-                    else S2 = S;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            FX_T(5);   // samples settled by the whole wavefront
-        }
-        if (valid) {
-            const uint32_t px = colour_exact(S0, S1, S2);
-            size_t off;
-            if (p.rgb_table) {
-                const uint32_t img = trow / p.rows_per_img;
-                off = (size_t)(reinterpret_cast<uintptr_t>(p.rgb_table[img]) - reinterpret_cast<uintptr_t>(p.rgb)) +
-                      (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch;
-            } else {
-                off = (size_t)trow * 8 * p.pitch;
-            }
-            uint8_t* o = p.rgb + off + (size_t)x * p.pitch + (size_t)(m0 + g) * 24 + y * 3;
-            o[0] = (uint8_t)px;
-            o[1] = (uint8_t)(px >> 8);
-            o[2] = (uint8_t)(px >> 16);
-        }
-        FX_T(6);   // colour, stores
-    };
-
-    for (;;) {
-        const bool flush = chunk >= nchunks;   // behind this wavefront's last chunk: what is left in the list
-        const Mask m = m_next;
-        uint32_t chunk_next = 0xFFFFFFFFu;
-        if (!flush) {
-            chunk_next = take_chunk();
-            m_next = load_mask(chunk_next);    // a chunk ahead
-        }
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int w = 0; w < MW; ++w) cnt += __popc(m.w[w]);
-        uint32_t incl = 0, total = 0;
-        if (__ballot(cnt != 0)) {   // wave-uniform
-            incl = wave_scan_incl(cnt);
-            total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        settled += total;
-        FX_T(1);   // mask load, count, scan
-        uint32_t done = 0;   // marked pixels of this chunk that are in the list or settled
-        if (!p.skip_exact && (flush || total)) do {   // (skip_exact, timing experiments: marked pixels are counted, not settled)
-            const uint32_t take = min((uint32_t)(FX_LIST + 64) - nl, total - done);
-            if (take) {
-                // the chunk's marked pixels [done, done + take), in the order of this mask, behind what the list holds
-                uint32_t o = nl + (incl - cnt) - done;   // (an ordinal below `done` wraps to a huge value: not listed in this round)
-                const uint32_t byte0 = chunk * (FX_CHUNK_TILES * UMASK_TILE_BYTES) + lane;   // this lane's byte of the chunk's first tile
-#pragma unroll
-                for (int w = 0; w < MW; ++w) {
-                    uint32_t bits = m.w[w];
-                    while (bits) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(bits);
-                        bits &= bits - 1;
-                        // bit b of word w: bit b & 7 of the byte of tile 4 w + b / 8
-                        if (o - nl < take) s_list[o] = ((byte0 + ((uint32_t)w * 4u + (b >> 3)) * UMASK_TILE_BYTES) << 3) | (b & 7u);
-                        o++;
-                    }
-                }
-                nl += take;
-                done += take;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            FX_T(2);   // list
-            // whole batches; behind the last chunk also the rest
-            const uint32_t nfull = nl & ~63u, upto = flush ? nl : nfull;
-            for (uint32_t e0 = 0; e0 < upto; e0 += 64) process(e0, nl);
-            if (upto < nl) {
-                // what did not fill a batch moves to the front and waits
-                const uint32_t keep = lane < nl - upto ? s_list[upto + lane] : 0u;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lane < nl - upto) s_list[lane] = keep;
-                nl -= upto;
-            } else {
-                nl = 0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        } while (done < total);
-        if (flush) break;
-        chunk = chunk_next;
-    }
-#ifdef KPEG_FX_STAMP
-    {
-        const uint32_t w = blockIdx.x * FX_WAVES + wave;
-        if (lane < 9 && w < 8192) {
-            unsigned long long v = 0;
-            for (int k = 0; k < 8; ++k) v = (int)lane == k ? fx_acc[k] : v;
-            if (lane == 8) v = fx_r0 | ((__builtin_amdgcn_s_memrealtime() - fx_r0) << 40);   // start (100 MHz ticks), duration << 40
-            g_fx_stamp[w * 16 + lane] = v;
-        }
-    }
-#endif
-    // The workgroup's last wavefront adds the workgroup's count of settled pixels to the statistics (spread over 256 words:
+    // The workgroup's last wavefront adds the workgroup's count of unsafe pixels to the statistics (spread over 256 words:
     // a single hot word serialises in L2) and takes the workgroup's end-of-call ticket.
     uint32_t last_of_wg = 0;
-    if (lane == 0) {
-        if (settled) atomicAdd(&s_wg[1], settled);
+    if (tid == 0) {
+        if (nq_total) atomicAdd(&s_wg[1], nq_total);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        last_of_wg = atomicAdd(&s_wg[0], 1u) == (uint32_t)FX_WAVES - 1 ? 1u : 0u;
+        last_of_wg = atomicAdd(&s_wg[0], 1u) == (uint32_t)K4_WAVES - 1 ? 1u : 0u;
     }
     if (!__builtin_amdgcn_readfirstlane((int)last_of_wg)) return;
     uint32_t dep = 0;
-    if (lane == 0) {
+    if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const uint32_t n = s_wg[1];
         if (n && p.stats) dep = atomicAdd(&p.stats[blockIdx.x & 255], n);

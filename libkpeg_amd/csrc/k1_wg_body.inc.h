@@ -141,12 +141,12 @@
         }
     } else if (p == 0) {
         const uint32_t nwg = (nsub + OWN - 1) / OWN;   // the workgroups that get here
-        if (a.mcu_start) {
+        if (a.tile_start) {
             // compact coefficient stream: nothing to clear but the tiles' first-record table (a tile whose first block a
             // corrupt stream never starts then reads as empty)
-            const uint32_t tper = (a.nstart + 1 + nwg - 1) / nwg;
-            const uint32_t t0 = min(a.nstart + 1, g * tper), t1 = min(a.nstart + 1, t0 + tper);
-            for (uint32_t q = t0 + t; q < t1; q += SYNC_WG) a.mcu_start[q] = 0u;
+            const uint32_t tper = (a.ntiles + 1 + nwg - 1) / nwg;
+            const uint32_t t0 = min(a.ntiles + 1, g * tper), t1 = min(a.ntiles + 1, t0 + tper);
+            for (uint32_t q = t0 + t; q < t1; q += SYNC_WG) a.tile_start[q] = 0u;
         } else {
             const uint64_t per = (a.coef_n16 + nwg - 1) / nwg;
             const uint64_t b0 = (uint64_t)g * per, b1 = min(a.coef_n16, b0 + per);

@@ -145,14 +145,15 @@
         uint32_t dcrange = 0;
         // compact stream: where this lane's records go (K1 counted them: the scan gives every lane its first ordinal), and
         // which block of which K4 tile the next block to start is (global block gbase + b = 24 tile + bmn)
-        uint32_t ord = 0, ord_end = 0, bmn = 0, bm_cur = 0;
+        uint32_t ord = 0, ord_end = 0, bmn = 0, tn = 0, bm_cur = 0;
         uint32_t nq = 0;                     // records in the ring
         uint32_t* const ring = reinterpret_cast<uint32_t*>(&s_pre[threadIdx.x]);
         if (COMPACT) {
             ord = wrec_g + s_prer[threadIdx.x];
             ord_end = min(ord + nrec_i, a.rec_cap);
             const uint32_t gbn = seg_mcu0 * 3 + b;
-            bmn = gbn % TILE_BLOCKS;
+            tn = gbn / TILE_BLOCKS;
+            bmn = gbn - tn * TILE_BLOCKS;
             bm_cur = bmn ? bmn - 1 : TILE_BLOCKS - 1;   // the block in progress at entry (if any)
         }
         float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
@@ -214,11 +215,12 @@
                 keep = (e >> 25) & 1u ? E_REC : 0u; // E_KEEP
                 if (COMPACT) {
                     bm_cur = bmn;
-                    // a luma block opens an MCU: its records begin here.  gb is a multiple of 3 there, and x * (inverse of 3 mod 2^32) is
-                    // x / 3 for a multiple of 3 and something above 2^32 / 3 for everything else: one multiply says both
-                    const uint32_t mi = gb * 0xAAAAAAABu;
-                    if (mi < a.nstart) a.mcu_start[mi] = ord;
-                    bmn = bmn == TILE_BLOCKS - 1 ? 0u : bmn + 1;
+                    if (bmn == 0 && tn <= a.ntiles) a.tile_start[tn] = ord;   // this tile's records begin here
+                    bmn++;
+                    if (bmn == TILE_BLOCKS) {
+                        bmn = 0;
+                        tn++;
+                    }
                     a.dc16[gb] = (int16_t)n;
                 } else {
                     a.coef[(size_t)gb << 6] = (int16_t)n;
@@ -302,9 +304,9 @@
         tail_chroma = (int)cur_chroma;
         if (k != 0 && pend != 0)   // (pend == 0: the lane did nothing, or the segment's last block ended here -- then k == 0)
             share = make_int4(__float_as_int(Asum), nnz, SH_OPEN | ((int)ncw < 0 ? 0 : SH_CORNER) | ((fl & FL_INHEAD) ? 0 : SH_STARTED), 0);
-        // end of the last MCU: by the lane in which the stream's last block ended (bits after it are ignored, as the
+        // end of the last tile: by the lane in which the stream's last block ended (bits after it are ignored, as the
         // reference ignores them: a later lane never gets here)
-        if (COMPACT && (fl & FL_LAST) && g.seg + 1 == nseg) a.mcu_start[a.nstart] = ord;
+        if (COMPACT && (fl & FL_LAST) && g.seg + 1 == nseg) a.tile_start[a.ntiles] = ord;
         // the last sub-sequence of a segment must have produced the segment's last block, all of it
         if (g.li + 1 == (stuffed ? nsub : a.sub_base[g.seg + 1] - first)) {
             if (b < blk_limit) err |= 128;

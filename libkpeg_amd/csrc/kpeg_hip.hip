@@ -54,18 +54,13 @@ struct kpeg_hip_ctx {
     size_t pad_cap = 0;
     void* d_ebound = nullptr;  // per-block error bounds for K4 (written by K2 or k_ebound)
     size_t ebound_cap = 0;
-    // compact coefficient stream between K2 and K4 (sparse streams whose MCU rows are whole K4 tiles): records, DC values, first record of every MCU
+    // compact coefficient stream between K2 and K4 (sparse streams whose MCU rows are whole K4 tiles): records, DC values, first record of every tile
     void* d_rec = nullptr;
     size_t rec_cap = 0;
     void* d_dc16 = nullptr;
     size_t dc16_cap = 0;
     void* d_tstart = nullptr;
     size_t tstart_cap = 0;
-    void* d_umask = nullptr;    // K4's unsafe-pixel mask, 64 bytes per tile (k_idct_colour_fast writes it, k_fixup reads it)
-    size_t umask_cap = 0;
-    void* d_urows = nullptr;    // ... and a slot per lane and tile for the rows that have a marked pixel (4 KB per tile, touched where marked only)
-    size_t urows_cap = 0;
-    int fx_wgs_per_cu = 1;      // k_fixup's workgroups a CU holds at once
     int coef_layout = 0;       // test hook: 0 = chosen per call, 1 = always the dense layout, 2 = the compact stream wherever it is possible
     EntropyScratch ent;        // K0..K3 work buffers
     // [0] unused, [1] entropy error flag, [2] sync passes, [16..271] K4 exact-pixel counters
@@ -74,7 +69,7 @@ struct kpeg_hip_ctx {
     uint32_t* h_status_dev = nullptr;  // its device address
     bool status_clean = false;     // the device words are zero (the previous call's last kernel cleared them)
 
-    enum { EV_BEGIN, EV_UNSTUFF, EV_SYNC, EV_SCAN, EV_WRITE, EV_DC, EV_IDCT, EV_FIXUP, EV_COUNT };
+    enum { EV_BEGIN, EV_UNSTUFF, EV_SYNC, EV_SCAN, EV_WRITE, EV_DC, EV_IDCT, EV_COUNT };
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t switch_ev = nullptr;   // kpeg_hip_set_stream: the new stream waits for what is queued on the old one
     bool ev_rec[EV_COUNT] = {};
@@ -197,14 +192,6 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
             const int v = std::atoi(s);
             if (v > 0) ctx->k4_wgs_per_cu = v;
         }
-        {
-            int nx = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nx, k_fixup<true>, FX_THREADS, 0) == hipSuccess && nx > 0) ctx->fx_wgs_per_cu = nx;
-            if (const char* s = std::getenv("KPEG_FX_WGS_PER_CU")) {   // experiments
-                const int v = std::atoi(s);
-                if (v > 0) ctx->fx_wgs_per_cu = v;
-            }
-        }
         if (const char* s = std::getenv("KPEG_FORCE_K0")) ctx->force_k0 = std::atoi(s) ? 1u : 0u;
         {
             int nf = 0;
@@ -259,8 +246,6 @@ extern "C" void kpeg_hip_destroy(kpeg_hip_ctx* ctx)
     if (ctx->d_rec) (void)hipFree(ctx->d_rec);
     if (ctx->d_dc16) (void)hipFree(ctx->d_dc16);
     if (ctx->d_tstart) (void)hipFree(ctx->d_tstart);
-    if (ctx->d_umask) (void)hipFree(ctx->d_umask);
-    if (ctx->d_urows) (void)hipFree(ctx->d_urows);
     entropy_scratch_free(&ctx->ent);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -370,8 +355,7 @@ extern "C" int kpeg_hip_sync(kpeg_hip_ctx* ctx)
         ctx->timings.huff_write_ms = span(C::EV_SCAN, C::EV_WRITE);
         ctx->timings.dc_ms = span(C::EV_WRITE, C::EV_DC);
         ctx->timings.idct_ms = ctx->ev_rec[C::EV_DC] ? span(C::EV_DC, C::EV_IDCT) : span(C::EV_BEGIN, C::EV_IDCT);
-        ctx->timings.fixup_ms = span(C::EV_IDCT, C::EV_FIXUP);
-        ctx->timings.total_ms = ctx->ev_rec[C::EV_FIXUP] ? span(C::EV_BEGIN, C::EV_FIXUP) : span(C::EV_BEGIN, C::EV_IDCT);
+        ctx->timings.total_ms = span(C::EV_BEGIN, C::EV_IDCT);
         if (!ctx->ev_rec[C::EV_IDCT]) ctx->timings.total_ms = span(C::EV_BEGIN, C::EV_DC);
     }
     return rc;
@@ -407,9 +391,7 @@ static void natural_qtables(const kpeg_frame* f, QTables* qt)
         for (int k = 0; k < 64; ++k) qt->q[t][KPEG_ZZ_TO_NATURAL[k]] = f->qt[t][k];
 }
 
-// K4 launch: rows [0, mcu_rows) of d_coef -> d_rgb.  ctx->d_ebound must hold the blocks' error bounds.  Two kernels: the fast
-// transform, which marks the pixels it cannot vouch for, and k_fixup, which settles those in the reference's order and is the
-// call's last kernel (status words to the host mirror).
+// K4 launch: rows [0, mcu_rows) of d_coef -> d_rgb.  ctx->d_ebound must hold the blocks' error bounds.
 static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_coef, uint8_t* d_rgb, uint32_t mcu_rows,
                        uint8_t* const* d_rgb_table = nullptr, uint32_t rows_per_img = 0, bool compact = false)
 {
@@ -435,17 +417,14 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
     p.skip_exact = ctx->idct_mode == 2;
     p.rec = compact ? (const uint32_t*)ctx->d_rec : nullptr;
     p.dc16 = compact ? (const int16_t*)ctx->d_dc16 : nullptr;
-    p.mcu_start = compact ? (const uint32_t*)ctx->d_tstart : nullptr;
-    p.rec_cap = compact ? (uint32_t)std::min<size_t>(ctx->rec_cap / 4 - 16, 0xFFFFFFF0u) : 0u;   // (k_fixup reads up to four words from a record on: inside the buffer)
-    p.umask = nullptr;
-    p.urows = nullptr;
+    p.tile_start = compact ? (const uint32_t*)ctx->d_tstart : nullptr;
+    p.rec_cap = compact ? (uint32_t)std::min<size_t>(ctx->rec_cap / 4, 0xFFFFFFFFu) : 0u;
     if (ctx->idct_mode == 1) {
         p.tiles_w = 0;
         p.ntiles = 0;
         p.tiles_w_magic = 0;
         p.tiles_w_shift = 0;
         hipLaunchKernelGGL(k_idct_colour_exact, dim3(p.mcus_w * mcu_rows), dim3(64), 0, ctx->stream, p, qt);
-        mark(ctx, kpeg_hip_ctx::EV_IDCT);
     } else {
         p.tiles_w = (p.mcus_w + TILE_MCUS - 1) / TILE_MCUS;
         p.ntiles = p.tiles_w * mcu_rows;
@@ -459,25 +438,11 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
             p.tiles_w_magic = d > 1 ? (uint32_t)((((uint64_t)1 << (32 + sft)) + d - 1) / d) : 0;
             p.tiles_w_shift = sft;
         }
-        const uint32_t nchunks = (p.ntiles + FX_CHUNK_TILES - 1) / FX_CHUNK_TILES;
-        int rc = grow(ctx, &ctx->d_umask, &ctx->umask_cap, (size_t)nchunks * FX_CHUNK_TILES * UMASK_TILE_BYTES);
-        if (rc) return rc;
-        p.umask = (uint8_t*)ctx->d_umask;
-        if ((rc = grow(ctx, &ctx->d_urows, &ctx->urows_cap, (size_t)p.ntiles * 64 * UROW_BYTES))) return rc;
-        p.urows = (uint8_t*)ctx->d_urows;
         const uint32_t resident = (uint32_t)ctx->num_cus * (uint32_t)ctx->k4_wgs_per_cu;
         const uint32_t want = (p.ntiles + K4_WAVES - 1) / K4_WAVES;   // at least a tile per wavefront
         const uint32_t grid = want < resident ? want : resident;
         if (compact) hipLaunchKernelGGL(k_idct_colour_fast<true>, dim3(grid), dim3(K4_THREADS), 0, ctx->stream, p, qt);
         else hipLaunchKernelGGL(k_idct_colour_fast<false>, dim3(grid), dim3(K4_THREADS), 0, ctx->stream, p, qt);
-        mark(ctx, kpeg_hip_ctx::EV_IDCT);
-        // as many workgroups as the device holds at once (each hands the chunks of the mask it owns to its wavefronts as they go), at most one per two chunks a wavefront
-        const uint32_t fx_resident = (uint32_t)ctx->num_cus * (uint32_t)ctx->fx_wgs_per_cu;
-        const uint32_t fx_want = (nchunks + 2 * FX_WAVES - 1) / (2 * FX_WAVES);
-        const uint32_t fx_grid = fx_want < fx_resident ? fx_want : fx_resident;
-        if (compact) hipLaunchKernelGGL(k_fixup<true>, dim3(fx_grid), dim3(FX_THREADS), 0, ctx->stream, p, qt);
-        else hipLaunchKernelGGL(k_fixup<false>, dim3(fx_grid), dim3(FX_THREADS), 0, ctx->stream, p, qt);
-        mark(ctx, kpeg_hip_ctx::EV_FIXUP);
     }
     HIPCHK(ctx, hipGetLastError());
     return KPEG_HIP_OK;
@@ -486,7 +451,7 @@ static int launch_idct(kpeg_hip_ctx* ctx, const kpeg_frame* f, const int16_t* d_
 __global__ void k_status_flush(uint32_t* status, uint32_t* h_status, uint32_t keep) { status_epilogue(status, h_status, 1, keep, 0); }
 
 // End of an enqueued call: the status words reach the host mirror and the device words are zero again --
-// done by k_fixup's last wavefront when K4 + k_fixup were the call's last kernels, else by a one-wavefront kernel.
+// done by K4's last wavefront when K4 was the call's last kernel, else by a one-wavefront kernel.
 static int finish_async(kpeg_hip_ctx* ctx, bool k4_did_it)
 {
     if (!k4_did_it) {
@@ -520,6 +485,7 @@ extern "C" int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, 
     mark(ctx, kpeg_hip_ctx::EV_DC);
     rc = launch_idct(ctx, f, d_coef, d_rgb, f->height / 8);
     if (rc) return rc;
+    mark(ctx, kpeg_hip_ctx::EV_IDCT);
     return finish_async(ctx, ctx->idct_mode != 1);
 }
 
@@ -594,12 +560,12 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
         const uint64_t nrec = std::min<uint64_t>(bytes * 4, (uint64_t)nmcu * 3 * 63) + 64;
         if ((rc = grow(ctx, &ctx->d_rec, &ctx->rec_cap, nrec * 4))) return rc;
         if ((rc = grow(ctx, &ctx->d_dc16, &ctx->dc16_cap, (size_t)nmcu * 3 * 2 + 64))) return rc;
-        if ((rc = grow(ctx, &ctx->d_tstart, &ctx->tstart_cap, ((size_t)nmcu + 2) * 4))) return rc;
+        if ((rc = grow(ctx, &ctx->d_tstart, &ctx->tstart_cap, ((size_t)nmcu / TILE_MCUS + 2) * 4))) return rc;
         L.d_rec = (uint32_t*)ctx->d_rec;
         L.rec_cap = (uint32_t)std::min<uint64_t>(nrec, 0xFFFFFFFFu);
         L.d_dc16 = (int16_t*)ctx->d_dc16;
-        L.d_mcu_start = (uint32_t*)ctx->d_tstart;
-        L.nstart = nmcu;
+        L.d_tile_start = (uint32_t*)ctx->d_tstart;
+        L.ntiles = nmcu / TILE_MCUS;
     }
     L.spin_ticks = ctx->spin_ticks;
     L.fault = ctx->fault;
@@ -661,6 +627,7 @@ extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f
     if (rc) return rc;
     rc = launch_idct(ctx, f, (const int16_t*)ctx->d_coef, d_rgb, mcu_rows, nullptr, 0, compact);
     if (rc) return rc;
+    mark(ctx, kpeg_hip_ctx::EV_IDCT);
     return finish_async(ctx, ctx->idct_mode != 1);
 }
 
@@ -1219,16 +1186,6 @@ extern "C" int kpeg_hip_debug_words(kpeg_hip_ctx* ctx, uint32_t* out, int n)
     return KPEG_HIP_OK;
 }
 
-// test / analysis hook: K4's unsafe-pixel mask of the last call (64 bytes per tile: byte = lane of the tile, bit 7 - i = pixel column i)
-extern "C" int kpeg_hip_debug_umask(kpeg_hip_ctx* ctx, uint8_t* out, size_t n)
-{
-    if (!ctx || !out || !ctx->d_umask || n > ctx->umask_cap) return KPEG_HIP_E_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(out, ctx->d_umask, n, hipMemcpyDeviceToHost));
-    return KPEG_HIP_OK;
-}
-
 // test hook, host only (no device needed): the first-level Huffman tables as the kernels get them -- lut[4][512] (one symbol
 // per entry, [class * 2 + id]) and lutx[4][512] (K1's two-symbol entries, same order) -- for tests/test_tables.py, which checks every
 // two-symbol entry against two steps through the one-symbol table.  lut_bits receives LUT_BITS.
@@ -1249,14 +1206,6 @@ extern "C" int kpeg_hip_debug_entropy_stamps(int which, unsigned long long* out,
 {
     if (which < 0 || which > 1 || n > 8192 * 16) return -1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(kpeg_dev::g_ent_stamp), (size_t)n * 8, (size_t)which * 8192 * 16 * 8) == hipSuccess ? 0 : -2;
-}
-#endif
-#ifdef KPEG_FX_STAMP
-// diagnostic build only (tools/fx_clock.py): per-wavefront phase cycles of the last k_fixup launch
-extern "C" int kpeg_hip_debug_fx_stamps(unsigned long long* out, int n)
-{
-    if (n > 8192 * 16) n = 8192 * 16;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kpeg_dev::g_fx_stamp), (size_t)n * 8) == hipSuccess ? 0 : -2;
 }
 #endif
 #ifdef KPEG_K4_STAMP
