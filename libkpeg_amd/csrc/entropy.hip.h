@@ -1610,6 +1610,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const uint64_t tw1 = __builtin_amdgcn_s_memtime();
 #endif
 #define K2_S_START s_start
+#include "k2_scan.inc.h"
 #include "k2_core.inc.h"
 #undef K2_S_START
 }
@@ -1644,10 +1645,22 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     __shared__ uint32_t s_bits[STAGE_CAP];
     static_assert(sizeof(s_lutx) >= SYNC_WG * (sizeof(int4) + sizeof(uint32_t)), "K2's scan arrays take the place of run_exit's tables");
     (void)s_cnt;
+    // the hand-over from the workgroups before: every wavefront's part of their totals, its last record's exit state (two rounds), x_before
+    __shared__ int4 s_hsum[SYNC_WG / 64];
+    __shared__ uint32_t s_hrec[SYNC_WG / 64];
+    __shared__ uint64_t s_hx[2 * (SYNC_WG / 64) + 1];
     const bool stuffed = true;   // (the host takes this path for such calls only)
     const uint32_t nsub = ka.nsub_host, nseg = 1u, n_u = 0u;
     const uint32_t i0 = blockIdx.x * OWN;
     if (i0 >= nsub) return;
+#ifndef KPEG_FUSED_PRIO
+#define KPEG_FUSED_PRIO 2
+#endif
+    // K1's part is what the kernel waits for -- its chains of re-decodes, one lane after the other; K2's loops are bulk work that fills
+    // what issue slots are left.  On a SIMD the oldest wavefront is served first, so the workgroups dispatched last (they share their CU
+    // with two older ones, which are at their write loops by then) had their K1 parts end 25 us after the first ones' (tools/fused_timeline.py).
+    // Priority outranks age: K1 runs raised, K2 does not.
+    __builtin_amdgcn_s_setprio(KPEG_FUSED_PRIO);
     // ---- K1, pass 0 ----
     uint64_t k1_exit = 0, k1_as = 0;
     int4 k1_cnt = make_int4(0, 0, 0, 0);
@@ -1672,97 +1685,23 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         // (the body's thread 0 has published the totals, the last exit state and the assumption: a.gen != 0)
     }
     const uint32_t gi = blockIdx.x, ti = threadIdx.x;
-    // ---- every workgroup before this one: wait, add up, check ----
-    int4 f_sum = make_int4(0, 0, 0, 0);
-    uint32_t f_rec = 0;
-    int f_bad = 0;
-    auto ldw = [&](uint32_t h, uint32_t q) -> unsigned long long {
-        return __hip_atomic_load(&ka.pub[(size_t)h * PUB_WORDS + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    // Wavefront 0 waits for all of them, 64 first words per load, a chunk of 64 never looked at again once it was complete,
-    // two microseconds of sleep between looks: hundreds of workgroups wait here while others still decode on the same SIMDs.
-    if (ti < 64) {
-        const uint32_t nchunks = (gi + 63) / 64;
-        uint32_t rem = nchunks >= 32 ? 0xFFFFFFFFu : (1u << nchunks) - 1u;   // (<= 32 chunks: the grid is resident, < 2048 workgroups)
-        if (gi > 2048) f_bad = 2;
-        SpinGuard guard(FUSED_SPIN_TICKS);
-        while (rem && !f_bad) {
-            for (uint32_t c = 0; c < nchunks; ++c) {
-                if (!((rem >> c) & 1u)) continue;   // (wave-uniform)
-                const uint32_t h = c * 64 + ti;
-                const bool ok = h >= gi || (uint32_t)(ldw(h, 0) >> 32) == ka.gen;
-                if (__ballot(ok) == ~0ull) rem &= ~(1u << c);
-            }
-            if (rem) {
-                if (guard.expired()) f_bad = 2;
-                else __builtin_amdgcn_s_sleep(64);
-            }
-        }
-    }
-    if (__syncthreads_or(f_bad)) {
-        if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    // every workgroup before this one has published (its first word is there; the others are on their way at worst): add
-    // their totals up, check every assumption up to this workgroup's own
-    auto word = [&](uint32_t h, uint32_t q, int& bad) -> uint32_t {
-        SpinGuard guard(FUSED_SPIN_TICKS);
-        unsigned long long v = ldw(h, q);
-        while ((uint32_t)(v >> 32) != ka.gen) {
-            if (guard.expired()) {
-                bad = 2;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            v = ldw(h, q);
-        }
-        return (uint32_t)v;
-    };
-    uint64_t x_before = 0;   // the exit state of the sub-sequence before this workgroup's first
-    for (uint32_t h = ti; h < gi; h += SYNC_WG) {
-        f_sum = add4(f_sum, make_int4((int)word(h, 0, f_bad), (int)word(h, 1, f_bad), (int)word(h, 2, f_bad), (int)word(h, 3, f_bad)));
-        f_rec += word(h, 4, f_bad);
-        const uint64_t xh = (uint64_t)word(h, 5, f_bad) | ((uint64_t)word(h, 6, f_bad) << 32);
-        // the workgroup behind h assumed something: this one's own assumption if that is this workgroup
-        const uint64_t as = h + 1 < gi ? ((uint64_t)word(h + 1, 7, f_bad) | ((uint64_t)word(h + 1, 8, f_bad) << 32)) : k1_as;
-        if (as != X_NONE && as != xh && !f_bad) f_bad = 1;
-        if (h + 1 == gi) x_before = xh;
-    }
-    // (x_before sits with the thread that handled workgroup gi - 1: through LDS below)
-    const bool has_before = gi > 0 && ((gi - 1) % SYNC_WG) == ti;
-    f_sum = make_int4(wave_scan_incl(f_sum.x), wave_scan_incl(f_sum.y), wave_scan_incl(f_sum.z), wave_scan_incl(f_sum.w));
-    f_rec = wave_scan_incl(f_rec);
-    __syncthreads();   // (K1's last readers of s_red / s_redn and of s_lutx are done)
-    if ((ti & 63) == 63) {
-        s_red[ti >> 6] = f_sum;
-        s_redn[ti >> 6] = f_rec;
-    }
-    if (has_before) s_wexit[0] = x_before;
-    const int f_anybad = __syncthreads_or(f_bad);
-    if (f_anybad) {
-        if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (gi == 0 && ti == 0) ka.status[2] = 1u;   // launches of K1 that had work (the launches behind this kernel say more if they run)
-    int4 wsum_g = make_int4(0, 0, 0, 0);
-    uint32_t wrec_g = 0;
-    for (uint32_t q = 0; q < SYNC_WG / 64; ++q) {
-        wsum_g = add4(wsum_g, s_red[q]);
-        wrec_g += s_redn[q];
-    }
-    x_before = s_wexit[0];
-    // ---- what K1's lanes know, handed to K2's lanes: item j of the workgroup sits on lane j + wu there, on lane j here ----
+    __builtin_amdgcn_s_setprio(0);
+#if KPEG_SYNC_STATS
+    const uint64_t tw0 = __builtin_amdgcn_s_memtime();   // K1's part is over for the whole workgroup, its totals are published
+#endif
+    // ---- what K1's lanes know, handed to K2's lanes: item j of the workgroup sits on lane j + wu there, on lane j here; then K2's
+    // scan inside the workgroup.  None of it needs another workgroup: it is done before the wait below, not behind it. ----
     int4* const s_pre = reinterpret_cast<int4*>(s_lutx);
     uint32_t* const s_prer = s_lutx + SYNC_WG * 4;
     int4* const s_wred = s_red;
     uint32_t* const s_wredr = s_redn;
     uint64_t* const s_x = reinterpret_cast<uint64_t*>(s_lutx);
-    __syncthreads();   // (s_red, s_redn, s_wexit read)
+    __syncthreads();   // (K1's last readers of s_red / s_redn and of s_lutx are done)
     if (k1_own) s_x[ti - k1_wu] = k1_exit;
     __syncthreads();
     const uint32_t i = i0 + ti;
     const bool valid = ti < OWN && i < nsub;
-    const uint64_t x_prev = valid && i > 0 ? (ti > 0 ? s_x[ti - 1] : x_before) : 0ull;
+    uint64_t x_prev = valid && ti > 0 ? s_x[ti - 1] : 0ull;   // (lane 0's is the predecessor workgroup's last exit state: below)
     __syncthreads();
     if (k1_own) {
         s_pre[ti - k1_wu] = k1_cnt;
@@ -1772,6 +1711,89 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const int4 cnt_i = valid ? s_pre[ti] : make_int4(0, 0, 0, 0);
     const uint32_t nrec_i = valid ? s_prer[ti] : 0u;
     __syncthreads();
+#include "k2_scan.inc.h"
+    // ---- every workgroup before this one: wait for what it published, add it up, check its assumption ----
+    // Thread ti takes workgroups ti and ti + SYNC_WG (the grid is resident: fewer than 2 SYNC_WG of them).  A record's nine words are
+    // asked for together and looked at afterwards -- each says for itself whether it is there (value | call number << 32) -- and a
+    // thread polls until its records are whole: when the image's slowest workgroup publishes at last, the workgroups behind it have
+    // everything else in registers already and are one load away from their write loops.  (Round 2 waited for first words with
+    // one wavefront and 2 us of sleep between looks, then read every word through its own validation loop: eleven round trips one
+    // after the other, 25 us between the slowest K1 part's end and the K2 loops behind it.)
+    int4 f_sum = make_int4(0, 0, 0, 0);
+    uint32_t f_rec = 0;
+    int f_bad = gi >= 2 * SYNC_WG ? 2 : 0;
+    uint64_t xa = 0, xb = 0, asa = X_NONE, asb = X_NONE;   // last exit state and assumed entry state of the two workgroups this thread takes
+    {
+        const bool ha = ti < gi, hb = ti + SYNC_WG < gi && !f_bad;
+        bool oka = !ha || f_bad, okb = !hb;
+        auto load_rec = [&](uint32_t h, uint64_t& xe, uint64_t& as) -> bool {
+            const unsigned long long* pw = ka.pub + (size_t)h * PUB_WORDS;
+            unsigned long long v[PUB_WORDS];
+#pragma unroll
+            for (uint32_t q = 0; q < PUB_WORDS; ++q) v[q] = __hip_atomic_load(pw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (uint32_t q = 0; q < PUB_WORDS; ++q) ok = ok && (uint32_t)(v[q] >> 32) == ka.gen;
+            if (ok) {
+                f_sum = add4(f_sum, make_int4((int)(uint32_t)v[0], (int)(uint32_t)v[1], (int)(uint32_t)v[2], (int)(uint32_t)v[3]));
+                f_rec += (uint32_t)v[4];
+                xe = (uint64_t)(uint32_t)v[5] | ((uint64_t)(uint32_t)v[6] << 32);
+                as = (uint64_t)(uint32_t)v[7] | ((uint64_t)(uint32_t)v[8] << 32);
+            }
+            return ok;
+        };
+        SpinGuard guard(FUSED_SPIN_TICKS);
+        for (;;) {
+            if (!oka) oka = load_rec(ti, xa, asa);
+            if (!okb) okb = load_rec(ti + SYNC_WG, xb, asb);
+            if (!__ballot(!oka || !okb)) break;   // (wave-uniform: the wavefront polls until all its records are whole)
+            if (guard.expired()) {
+                f_bad = 2;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+#if KPEG_SYNC_STATS
+    const uint64_t tw1 = __builtin_amdgcn_s_memtime();   // this wavefront has every record it takes
+#endif
+    // the exit state each assumption has to match is the workgroup's before: one lane over, one wavefront over (through LDS), and for
+    // workgroup SYNC_WG the last of the first round's
+    {
+        const uint32_t lane = ti & 63, wave = ti >> 6;
+        if (lane == 63) {
+            s_hx[wave] = xa;
+            s_hx[SYNC_WG / 64 + wave] = xb;
+        }
+        f_sum = make_int4(wave_scan_incl(f_sum.x), wave_scan_incl(f_sum.y), wave_scan_incl(f_sum.z), wave_scan_incl(f_sum.w));
+        f_rec = wave_scan_incl(f_rec);
+        if (lane == 63) {
+            s_hsum[wave] = f_sum;
+            s_hrec[wave] = f_rec;
+        }
+        if (gi > 0 && ((gi - 1) % SYNC_WG) == ti) s_hx[2 * (SYNC_WG / 64)] = gi - 1 < (uint32_t)SYNC_WG ? xa : xb;   // x_before
+        __syncthreads();
+        const uint64_t la = (uint64_t)wave_shr1((uint32_t)xa) | ((uint64_t)wave_shr1((uint32_t)(xa >> 32)) << 32);
+        const uint64_t lb = (uint64_t)wave_shr1((uint32_t)xb) | ((uint64_t)wave_shr1((uint32_t)(xb >> 32)) << 32);
+        const uint64_t left_a = lane ? la : (wave ? s_hx[wave - 1] : 0ull);
+        const uint64_t left_b = lane ? lb : (wave ? s_hx[SYNC_WG / 64 + wave - 1] : s_hx[SYNC_WG / 64 - 1]);
+        if (ti >= 1 && ti < gi && asa != X_NONE && asa != left_a) f_bad |= 1;
+        if (ti + SYNC_WG < gi && asb != X_NONE && asb != left_b) f_bad |= 1;
+    }
+    const uint64_t x_before = gi > 0 ? s_hx[2 * (SYNC_WG / 64)] : 0ull;   // the exit state of the sub-sequence before this workgroup's first
+    if (ti == 0 && gi > 0 && k1_as != X_NONE && k1_as != x_before) f_bad |= 1;   // this workgroup's own assumption
+    if (__syncthreads_or(f_bad)) {
+        if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (gi == 0 && ti == 0) ka.status[2] = 1u;   // launches of K1 that had work (the launches behind this kernel say more if they run)
+    int4 wsum_g = make_int4(0, 0, 0, 0);
+    uint32_t wrec_g = 0;
+    for (uint32_t q = 0; q < SYNC_WG / 64; ++q) {
+        wsum_g = add4(wsum_g, s_hsum[q]);
+        wrec_g += s_hrec[q];
+    }
+    if (valid && ti == 0 && i > 0) x_prev = x_before;
     SubGeom g0;
     g0.seg = 0;
     g0.li = i0;
@@ -1779,9 +1801,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     g0.pend = 0;
     const uint32_t w0 = 0;
 #if KPEG_SYNC_STATS
-    const uint64_t tw0 = __builtin_amdgcn_s_memtime();
     uint32_t st_steps = 0;
-    const uint64_t tw1 = tw0;
 #endif
     uint32_t* const k2_start = s_start + k1_wu;
 #define K2_S_START k2_start

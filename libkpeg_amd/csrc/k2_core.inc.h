@@ -1,34 +1,11 @@
 // libkpeg_amd/csrc/k2_core.inc.h -- K2 from the point where a workgroup has its tables and its slice of the bit string in
-// LDS and every lane knows what K1 left for its sub-sequence: the scan inside the workgroup, the decode loop, the block
-// bounds, the error report.  Not a header: the text of a function body, included by k_write (after its loads and staging)
-// and by k_sync_write (after K1's work on the same workgroup).  Expects in scope: a (WriteArgs), S, COMPACT, S420, T, s_pre,
-// s_prer, s_wred, s_wredr, s_bits, K2_S_START (first bit of the chunk of lane threadIdx.x), stuffed, nsub, nseg, n_u, i0, i,
-// valid, cnt_i, nrec_i, x_prev, wsum_g, wrec_g, g0, w0 (and, stats builds, tw0, tw1, st_steps).
+// LDS, every lane knows what K1 left for its sub-sequence and the scan inside the workgroup is made (k2_scan.inc.h): the
+// workgroup's offset, the decode loop, the block bounds, the error report.  Not a header: the text of a function body,
+// included by k_write (after its loads and staging) and by k_sync_write (after K1's work on the same workgroup and the wait
+// for its predecessors).  Expects in scope: a (WriteArgs), S, COMPACT, S420, T, s_pre, s_prer, s_wred, s_wredr, s_bits,
+// K2_S_START (first bit of the chunk of lane threadIdx.x), stuffed, nsub, nseg, n_u, i0, i, valid, nrec_i, x_prev, wsum_g,
+// wrec_g, g0, w0 (and, stats builds, tw0, tw1, st_steps).
 
-    // (blocks, DC sums) before every sub-sequence: exclusive scan of cnt inside the workgroup (inside the wavefronts by
-    // shuffles, their totals through LDS: one barrier instead of the twenty of a scan that lives in LDS) ...
-    {
-        const int4 v = cnt_i;
-        const uint32_t vr = nrec_i;
-        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int4 inc = make_int4(wave_scan_incl(v.x), wave_scan_incl(v.y), wave_scan_incl(v.z), wave_scan_incl(v.w));
-        const uint32_t incr = COMPACT ? wave_scan_incl(vr) : 0u;
-        if (lane == 63) {
-            s_wred[wave] = inc;
-            if (COMPACT) s_wredr[wave] = incr;
-        }
-        __syncthreads();
-        int4 base = make_int4(0, 0, 0, 0);
-        uint32_t baser = 0;
-        for (uint32_t q = 0; q < SYNC_WG / 64; ++q)
-            if (q < wave) {
-                base = add4(base, s_wred[q]);
-                if (COMPACT) baser += s_wredr[q];
-            }
-        s_pre[threadIdx.x] = make_int4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
-        if (COMPACT) s_prer[threadIdx.x] = baser + incr - vr;   // exclusive
-        __syncthreads();   // (s_wred is used again below)
-    }
     // ... + the workgroup's offset, counted from the start of the restart segment.  A segment that began in
     // this workgroup re-bases on a neighbour's scan value; the one open at the workgroup's first
     // sub-sequence began in an earlier workgroup: its base is that workgroup's offset + its cnt up to there.

@@ -18,10 +18,27 @@ k1, k2 = stamps(0), stamps(1)
 nwg = int((k1[::8, 0] != 0).sum())
 w0 = np.arange(0, nwg * 8, 8)   # wavefront 0 of every workgroup
 t_start = k1[w0, 0].astype(np.int64)
-k1_end = k1[w0, 3].astype(np.int64) - t_start
+k1_end = k1[w0, 3].astype(np.int64) - t_start      # wavefront 0's own K1 part
+pub = k2[w0, 0].astype(np.int64) - t_start         # the workgroup's K1 part is over (all wavefronts), totals published
+got = k2[w0, 1].astype(np.int64) - t_start         # wavefront 0 has every predecessor's record it takes
 k2_beg = k2[w0, 2].astype(np.int64) - t_start
 k2_end = k2[w0, 4].astype(np.int64) - t_start
-print("wg   K1 part ends   K2 loop starts   K2 ends   (wait)   (K2 loop + epilogue)")
-for g in list(range(0, nwg, max(1, nwg // 20))) + [nwg - 1]:
-    print("%4d %10d %14d %12d %9d %12d" % (g, k1_end[g], k2_beg[g], k2_end[g], k2_beg[g] - k1_end[g], k2_end[g] - k2_beg[g]))
-print("slowest K1 part: wg", int(np.argmax(k1_end)), int(k1_end.max()), " last K2 end:", int(k2_end.max()), "wg", int(np.argmax(k2_end)))
+# s_memtime counts per XCD (the XCDs' counters are far apart); s_memrealtime (100 MHz) is one clock for the chip.  Every wavefront stamped
+# both at the end of its K1 part (k1[:, 3] / k1[:, 4]) and at the end of K2 (k2[:, 4] / k2[:, 5]): ticks per 10 ns from those, then every
+# s_memtime stamp of a wavefront goes to the common clock.
+tm3, rt3 = k1[w0, 3].astype(np.float64), k1[w0, 4].astype(np.float64)
+tw4, rt4 = k2[w0, 4].astype(np.float64), k2[w0, 5].astype(np.float64)
+ratio = np.median((tw4 - tm3) / np.maximum(rt4 - rt3, 1))
+r0 = (rt3 - (tm3 - k1[w0, 0].astype(np.float64)) / ratio).min()   # the first workgroup's start
+def absolute(col):   # 10 ns units since the first workgroup started
+    return rt3 + (col.astype(np.float64) - tm3) / ratio - r0
+a_k1, a_pub, a_got, a_beg, a_end = absolute(k1[w0, 3]), absolute(k2[w0, 0]), absolute(k2[w0, 1]), absolute(k2[w0, 2]), absolute(k2[w0, 4])
+latest_pub_before = np.concatenate([[0.0], np.maximum.accumulate(a_pub)[:-1]])   # when the last of workgroups 0..g-1 published
+print("shader clock %.0f MHz; times in us since the first workgroup started" % (ratio * 100))
+print("  wg  wave0 K1 ends  published  last pred. published  wave0 records in  K2 loop starts  K2 ends  hand-over (K2 start - max(published, last pred.))")
+ho = a_beg - np.maximum(a_pub, latest_pub_before)
+for g in list(range(0, nwg, max(1, nwg // 24))) + [nwg - 1]:
+    print("%4d %12.2f %10.2f %20.2f %17.2f %15.2f %8.2f %10.2f" % (g, a_k1[g] / 100, a_pub[g] / 100, latest_pub_before[g] / 100, a_got[g] / 100, a_beg[g] / 100, a_end[g] / 100, ho[g] / 100))
+print("last to publish: wg %d at %.2f us; last K2 end %.2f us" % (int(np.argmax(a_pub)), a_pub.max() / 100, a_end.max() / 100))
+print("hand-over: median %.2f us, 90 %% %.2f, max %.2f; of the workgroups behind the last to publish: median %.2f" % (
+    np.median(ho) / 100, np.percentile(ho, 90) / 100, ho.max() / 100, np.median(ho[int(np.argmax(a_pub)) + 1:]) / 100 if int(np.argmax(a_pub)) + 1 < nwg else 0))
