@@ -24,6 +24,12 @@ namespace kpeg
     {
         public:
             Image();
+            /// A copy owns its pixels: a source that still has them with the decoder (setLazySource) is asked for them first, so that
+            /// no copy depends on device memory which a later decode reuses.
+            Image( const Image& other );
+            Image& operator=( const Image& other );
+            Image( Image&& ) = default;
+            Image& operator=( Image&& ) = default;
 
             /// Tiles MCUs row-major into the pixel store and crops padding (reference
             /// src/Image.cpp:20-86).  Kept for API compatibility; the decoder uses adoptRGB8().

@@ -134,6 +134,10 @@ int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8
  * more than it has: undefined behaviour, so nothing to be bit-identical with but its output for the same scan at the
  * padded size -- which is what the tests pin.)  Every other entry point keeps the multiple-of-8 contract. */
 
+/* The number of calls that have written pixels into the context's resident buffer so far.  A caller that leaves a decoded image
+ * there (kpeg_hip_decode_scan_resident) notes it and checks it before kpeg_hip_download_bands: any later decode, batch or
+ * sharded call on the context changes it, and the pixels are then another picture's. */
+unsigned long long kpeg_hip_resident_generation(const kpeg_hip_ctx* ctx);
 /* The same decode with the pixels left on the device, in a buffer the context owns (valid until the context's next
  * decode), and their download in row bands through two pinned bounce buffers: while band k+1 crosses PCIe, `sink` is
  * called with band k (from the calling thread), e.g. to fwrite it -- Image::dumpRawData's 99.5 MB (8K) then reach the

@@ -60,7 +60,7 @@ EXPORTS = [
     "kpeg_hip_idct_colour", "kpeg_hip_decode_scan", "kpeg_hip_decode_batch", "kpeg_hip_decode_batch_dev",
     "kpeg_hip_idct_colour_dev", "kpeg_hip_decode_scan_dev", "kpeg_hip_decode_stripe_dev",
     "kpeg_hip_entropy_decode_dev", "kpeg_hip_set_idct_mode", "kpeg_hip_decode_sharded", "kpeg_hip_decode_sharded_dev",
-    "kpeg_hip_decode_scan_resident", "kpeg_hip_download_bands",
+    "kpeg_hip_decode_scan_resident", "kpeg_hip_download_bands", "kpeg_hip_resident_generation",
 ]
 
 _lib = None

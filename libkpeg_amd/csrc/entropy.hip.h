@@ -292,7 +292,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
 //    KPEG_HIP_E_DEVICE instead of the queue hanging.
 constexpr unsigned long long K0_SPIN_TICKS = 50000ull;        // 0.5 ms (a predecessor's 8 KiB take microseconds), then the fallback
 constexpr unsigned long long K1_SPIN_TICKS = 2000000000ull;   // 20 s: a predecessor's wait includes the whole chain before it
-constexpr unsigned long long FUSED_SPIN_TICKS = 100000ull;    // 1 ms: k_sync_write's waits; then the launches behind it take over
+constexpr unsigned long long FUSED_SPIN_TICKS = 30000ull;     // 0.3 ms (three times what the kernel takes on an 8K image): k_sync_write's waits; then the launches behind it take over
 struct SpinGuard {
     unsigned long long t0 = 0, limit;
     uint32_t polls = 0;
@@ -1982,10 +1982,14 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     if constexpr (SB < SUBSEQ_DENSE) {
         fuse = stuffed && L.d_tile_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= L.fused_slots;
         if (fuse) {
-            void* const before = S->d_flags;
+            const size_t cap_before = S->flags_cap;
             if ((rc = ent_grow(&S->d_flags, &S->flags_cap, (size_t)nwg_cap * PUB_WORDS * sizeof(unsigned long long), L.stream, err))) return rc;
-            if (S->d_flags != before) ENT_HIP(hipMemsetAsync(S->d_flags, 0, S->flags_cap, L.stream));
-            if (++S->gen == 0) ++S->gen;
+            bool wipe = S->flags_cap != cap_before;   // (a new allocation -- even at the old address -- holds anything)
+            if (++S->gen == 0) {
+                ++S->gen;   // 0 is "not that path"
+                wipe = true;   // the call numbers start over: nothing an earlier call published may pass for this one's
+            }
+            if (wipe) ENT_HIP(hipMemsetAsync(S->d_flags, 0, S->flags_cap, L.stream));
             sa.gen = wa.gen = S->gen;
             sa.pub = (unsigned long long*)S->d_flags;
             sa.pass = 0;
@@ -2017,6 +2021,13 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
 // four times longer sub-sequences mean a quarter of the rounds (each with its fixed cost) for the same
 // sequential chain; K2 pays ~40-70 % for them, K1 gains more (measured 1..19 bits per pixel; the
 // switch-over by K1 + K2 on synthetic fields and on tiled photographs, 4K and 8K: tools/subseq_choice.py).
+// the one rule for the sub-sequence size (the launcher below and the caller's choice of the coefficient layout both go by it)
+static bool entropy_dense_subseq(int forced, bool sub420, uint64_t bytes, uint64_t nmcu)
+{
+    const uint64_t bits = bytes * 8, px = nmcu * 64;
+    return forced ? forced >= SUBSEQ_DENSE : (sub420 || bits >= px * 4 || (bits >= px * 3 && px >= (4u << 20)));
+}
+
 static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, const EntropyLaunch& L, hipEvent_t* ev, bool* ev_rec,
                                  std::string* err)
 {
@@ -2026,8 +2037,7 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     // K1 1.13 ms with 384-bit sub-sequences, 1.54 ms with 96)
     // (from 3 bits per pixel on pictures of 4 Mpixel and more, where somewhere a chain of rounds is long; from 4 on small ones:
     // lena.jpg, 512 x 512 at 3.2 bits per pixel, takes 0.15 ms with the short sub-sequences and 0.19 ms with the long ones)
-    const uint64_t bits = bytes * 8, px = (uint64_t)L.nmcu * 64;
-    const bool dense = L.subseq ? L.subseq >= SUBSEQ_DENSE : (L.sub420 != 0 || bits >= px * 4 || (bits >= px * 3 && px >= (4u << 20)));
+    const bool dense = entropy_dense_subseq(L.subseq, L.sub420 != 0, bytes, L.sub420 ? (uint64_t)L.nmcu * 4 : (uint64_t)L.nmcu);   // (a 4:2:0 MCU is 256 pixels)
     return dense ? entropy_decode_launch_s<SUBSEQ_DENSE>(S, tabs, L, ev, ev_rec, err)
                  : entropy_decode_launch_s<SUBSEQ_SPARSE>(S, tabs, L, ev, ev_rec, err);
 }

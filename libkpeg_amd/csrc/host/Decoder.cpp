@@ -462,7 +462,10 @@ namespace kpeg
             if ( rc == KPEG_HIP_OK )
             {
                 Image* self = &image_;
-                image_.setLazySource( [ctx, f, self]( const Image::BandSink& sink ) {
+                // (the generation of the pixels this decode left in the context's buffer: a later decode bumps it, and a source that
+                // somebody kept beyond that -- dumpRawData() leaves it in place -- answers "gone" instead of another picture's pixels)
+                const unsigned long long gen = kpeg_hip_resident_generation( ctx );
+                image_.setLazySource( [ctx, f, self, gen]( const Image::BandSink& sink ) {
                     struct Tramp
                     {
                         static int call( void* user, uint32_t row0, uint32_t rows, const uint8_t* p, size_t )
@@ -471,6 +474,8 @@ namespace kpeg
                         }
                     };
                     (void)self;
+                    if ( kpeg_hip_resident_generation( ctx ) != gen )
+                        return false;
                     return kpeg_hip_download_bands( ctx, &f, 0, &Tramp::call, const_cast<Image::BandSink*>( &sink ) ) == KPEG_HIP_OK;
                 } );
             }

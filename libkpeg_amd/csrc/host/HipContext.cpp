@@ -42,10 +42,12 @@ namespace kpeg
         namespace
         {
             Image* g_resident = nullptr;
+            std::mutex g_resident_mutex;
         }
 
         void claimResident( Image* owner )
         {
+            std::lock_guard<std::mutex> lock( g_resident_mutex );
             if ( g_resident && g_resident != owner )
                 g_resident->materialise();   // the device buffer is about to be reused
             g_resident = owner;
@@ -53,6 +55,7 @@ namespace kpeg
 
         void releaseResident( Image* owner )
         {
+            std::lock_guard<std::mutex> lock( g_resident_mutex );
             if ( g_resident == owner )
                 g_resident = nullptr;
         }

@@ -15,6 +15,26 @@ namespace kpeg
     {
     }
 
+    Image::Image( const Image& o ) :
+        filename_{ o.filename_ }, pixelPtr_{ nullptr }, flPixelPtr_{ o.flPixelPtr_ }, JPEGversion_{ o.JPEGversion_ }, comment_{ o.comment_ },
+        width_{ o.width_ }, height_{ o.height_ }
+    {
+        o.materialise();      // (the source keeps the pixels it fetched: both own a copy afterwards)
+        rgb8_ = o.rgb8_;
+        if ( o.pixelPtr_ )
+            pixelPtr_ = std::make_shared<std::vector<std::vector<Pixel>>>( *o.pixelPtr_ );
+    }
+
+    Image& Image::operator=( const Image& o )
+    {
+        if ( this != &o )
+        {
+            Image tmp( o );
+            *this = std::move( tmp );
+        }
+        return *this;
+    }
+
     // MCU n -> tile (n / tilesPerRow, n % tilesPerRow); pixel (8*tr + v, 8*tc + u) = block[.][v][u];
     // columns/rows beyond the image size are cropped (reference src/Image.cpp:26-84).
     void Image::createImageFromMCUs( const std::vector<MCU>& MCUVector )
@@ -114,6 +134,9 @@ namespace kpeg
             LOG(Logger::Level::ERROR) << "Unable to create dump file \'" + filename + "\'." << std::endl;
             return false;
         }
+        const bool streaming = lazy_ && !haveRGB;
+        if ( streaming )
+            std::setvbuf( f, nullptr, _IONBF, 0 );   // whole bands go down in one write each (before any other operation on the stream: ISO C 7.21.5.6)
         // header bytes are part of the bit-exact output (reference src/Image.cpp:124-127)
         std::fprintf( f, "P6\n# PPM dump created using libKPEG: https://github.com/TheIllusionistMirage/libKPEG\n%zu %zu\n255\n",
                       width_, height_ );
@@ -121,7 +144,6 @@ namespace kpeg
         if ( lazy_ && !haveRGB )
         {
             // the pixels are still with the decoder: band k is written while band k + 1 is on its way; nothing is assembled
-            std::setvbuf( f, nullptr, _IONBF, 0 );   // (whole bands go down in one write each)
             const std::size_t pitch = width_ * 3;
             auto source = lazy_;   // (kept: the file is one consumer; a later getPixelPtr() may still want the pixels)
             ok = source( [&]( std::size_t, std::size_t rows, const UInt8* p ) { return std::fwrite( p, 1, rows * pitch, f ) == rows * pitch; } );

@@ -78,6 +78,41 @@ extern "C" int kpeg_host_decode_file( const char* path, unsigned flags )
     }
 }
 
+// test hook (tests/test_gpu_decode.py): what holders of a decoded image see after the shared context has decoded something else.
+// Decodes `path_a`, takes (1) a COPY of the decoder's image while its pixels are still on the GPU and (2) writes the PPM (which
+// leaves the lazy source in place), decodes `path_b` with another decoder, then copies the pixels the copy and the first
+// decoder's own image hold into out_copy / out_own (cap bytes each).  Returns the number of pixel bytes of image A, 0 on failure.
+extern "C" size_t kpeg_host_test_image_holders( const char* path_a, const char* path_b, uint8_t* out_copy, uint8_t* out_own, size_t cap )
+{
+    try
+    {
+        kpeg::JPEGDecoder a;
+        if ( !a.open( path_a ) || a.decodeImageFile() != kpeg::JPEGDecoder::DECODE_DONE )
+            return 0;
+        kpeg::Image copy = a.image();   // (must own its pixels from here on)
+        a.dumpRawData();
+        kpeg::Image assigned;
+        assigned = a.image();
+        {
+            kpeg::JPEGDecoder b;
+            if ( !b.open( path_b ) || b.decodeImageFile() != kpeg::JPEGDecoder::DECODE_DONE )
+                return 0;
+            b.dumpRawData();
+        }
+        const std::vector<kpeg::UInt8>& c = copy.getRGB8();
+        const std::vector<kpeg::UInt8>& o = a.image().getRGB8();
+        if ( c.size() > cap || o.size() != c.size() || assigned.getRGB8() != c )
+            return 0;
+        std::memcpy( out_copy, c.data(), c.size() );
+        std::memcpy( out_own, o.data(), o.size() );
+        return c.size();
+    }
+    catch ( ... )
+    {
+        return 0;
+    }
+}
+
 extern "C" size_t kpeg_host_restart_offsets( const uint8_t* scan, size_t n, uint64_t* offsets, size_t cap )
 {
     size_t k = 0;

@@ -47,6 +47,7 @@ struct kpeg_hip_ctx {
     size_t scan_cap = 0;
     void* d_rgb = nullptr;
     size_t rgb_cap = 0;
+    unsigned long long rgb_gen = 0;   // bumped by every call that writes pixels into d_rgb (kpeg_hip_resident_generation)
     uint32_t force_k0 = 0;      // debug key 8 / KPEG_FORCE_K0
     uint32_t fused_slots = 0;   // workgroups of k_sync_write resident at once; 0 = that kernel is not used (debug key 9 / KPEG_FUSED=0)
     uint32_t fused_slots_dev = 0;   // ... as the device reports it
@@ -499,6 +500,7 @@ extern "C" int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
     const size_t cbytes = nmcu * 192 * sizeof(int16_t), rbytes = (size_t)f->width * f->height * 3;
     if ((rc = grow(ctx, &ctx->d_coef, &ctx->coef_cap, cbytes))) return rc;
     if ((rc = grow(ctx, &ctx->d_rgb, &ctx->rgb_cap, rbytes))) return rc;
+    ctx->rgb_gen++;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_coef, coef, cbytes, hipMemcpyHostToDevice, ctx->stream));
     rc = kpeg_hip_idct_colour_dev(ctx, f, (const int16_t*)ctx->d_coef, (uint8_t*)ctx->d_rgb);
     if (rc) return rc;
@@ -517,7 +519,7 @@ static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t 
 {
     if (ctx->coef_layout == 1 || ctx->idct_mode == 1 || f->components == 1 || f->components == KPEG_FRAME_420) return false;
     if ((f->width / 8) % TILE_MCUS != 0) return false;
-    const bool dense = ctx->subseq ? ctx->subseq >= SUBSEQ_DENSE : scan_bytes * 8 >= nmcu * 64 * 4;   // entropy_decode_launch's rule
+    const bool dense = entropy_dense_subseq(ctx->subseq, f->components == KPEG_FRAME_420, scan_bytes, nmcu);   // (the launcher's own rule)
     if (ctx->coef_layout == 2) return true;
     // Measured end to end (tools/layout_sizes.sh, round 2, us dense / compact): 1920x1080 (12 MiB of dense coefficients)
     // 91 / 93, 3840x2160 (48 MiB) 111 / 108, 7680x4320 (190 MiB) 220 / 199, 16384x16384 2050 / 1270, 256 x 1080p 141 -> 207
@@ -729,6 +731,7 @@ extern "C" int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
     const size_t rbytes = (size_t)f->width * f->height * 3;
     if ((rc = grow(ctx, &ctx->d_scan, &ctx->scan_cap, scan_len + 64))) return rc;
     if ((rc = grow(ctx, &ctx->d_rgb, &ctx->rgb_cap, rbytes))) return rc;
+    ctx->rgb_gen++;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_scan, scan, scan_len, hipMemcpyHostToDevice, ctx->stream));
     rc = kpeg_hip_decode_scan_dev(ctx, f, (const uint8_t*)ctx->d_scan, scan_len, (uint8_t*)ctx->d_rgb);
     if (rc) return rc;
@@ -745,11 +748,14 @@ extern "C" int kpeg_hip_decode_scan_resident(kpeg_hip_ctx* ctx, const kpeg_frame
     const size_t rbytes = (size_t)f->width * f->height * 3;
     if ((rc = grow(ctx, &ctx->d_scan, &ctx->scan_cap, scan_len + 64))) return rc;
     if ((rc = grow(ctx, &ctx->d_rgb, &ctx->rgb_cap, rbytes))) return rc;
+    ctx->rgb_gen++;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_scan, scan, scan_len, hipMemcpyHostToDevice, ctx->stream));
     rc = kpeg_hip_decode_scan_dev(ctx, f, (const uint8_t*)ctx->d_scan, scan_len, (uint8_t*)ctx->d_rgb);
     if (rc) return rc;
     return kpeg_hip_sync(ctx);
 }
+
+extern "C" unsigned long long kpeg_hip_resident_generation(const kpeg_hip_ctx* ctx) { return ctx ? ctx->rgb_gen : 0ull; }
 
 extern "C" int kpeg_hip_download_bands(kpeg_hip_ctx* ctx, const kpeg_frame* f, uint32_t band_rows, kpeg_hip_band_sink sink, void* user)
 {
@@ -1017,6 +1023,7 @@ extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_fr
         }
         if ((rc = grow(L, &L->d_scan, &L->scan_cap, total + 64))) return rc;
         if ((rc = grow(L, &L->d_rgb, &L->rgb_cap, rbytes * c.n))) return rc;
+        L->rgb_gen++;
         if (total > L->h_scan_cap) {
             if (L->h_scan) (void)hipHostFree(L->h_scan);
             L->h_scan = nullptr;
@@ -1068,11 +1075,17 @@ static int decode_sharded_impl(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_f
     if (ngpu == 1) {
         st[0].r0 = 0, st[0].nr = mh, st[0].b0 = 0, st[0].b1 = scan_len;
     } else {
-        // RSTn positions in the still-stuffed scan: FF D0..D7 cannot occur inside entropy-coded data
-        std::vector<size_t> rst;
-        for (size_t i = 0; i + 1 < scan_len; ++i)
-            if (scan[i] == 0xFF && scan[i + 1] >= 0xD0 && scan[i + 1] <= 0xD7) rst.push_back(i);
+        // RSTn positions in the still-stuffed scan: FF D0..D7 cannot occur inside entropy-coded data.  memchr finds the FF bytes
+        // (one in ~200 bytes of a q75 stream) at memory speed: 35 MB of the 16384 x 16384 image in a few ms, where a byte loop took tens.
         const uint64_t nint = ((uint64_t)mw * mh + f->restart_interval - 1) / f->restart_interval;
+        std::vector<size_t> rst;
+        rst.reserve((size_t)nint);
+        for (const uint8_t* q = scan, *end = scan + scan_len - 1; q < end;) {
+            q = static_cast<const uint8_t*>(std::memchr(q, 0xFF, (size_t)(end - q)));
+            if (!q) break;
+            if (q[1] >= 0xD0 && q[1] <= 0xD7) rst.push_back((size_t)(q - scan));
+            ++q;
+        }
         if (rst.size() + 1 != nint) {
             root->last_error = "restart markers do not match the restart interval";
             return KPEG_HIP_E_STREAM;
@@ -1092,6 +1105,28 @@ static int decode_sharded_impl(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_f
             s.b1 = i1 >= nint ? scan_len : rst[i1 - 1];
         }
     }
+    if (root_is_device) {
+        // stripes travel GPU to GPU (hipMemcpyPeerAsync): direct access over xGMI is switched on once per pair; a pair without it is
+        // said so (the copy would be staged through the host: correct, and an order of magnitude slower)
+        for (int g = 1; g < ngpu; ++g) {
+            const int src = ctxs[g]->device, dst = root->device;
+            if (src == dst) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, src, dst) != hipSuccess || !can) {
+                root->last_error = "GPU " + std::to_string(src) + " has no peer access to GPU " + std::to_string(dst) + " (the stripes would be staged through host memory)";
+                return KPEG_HIP_E_UNSUPPORTED;
+            }
+            if (hipSetDevice(src) != hipSuccess) return KPEG_HIP_E_DEVICE;
+            const hipError_t pe = hipDeviceEnablePeerAccess(dst, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                root->last_error = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe);
+                (void)hipSetDevice(root->device);
+                return KPEG_HIP_E_DEVICE;
+            }
+            (void)hipGetLastError();   // (already enabled: not an error to carry along)
+        }
+        (void)hipSetDevice(root->device);
+    }
     const size_t pitch = (size_t)f->width * 3;
     // One host thread per GPU (a context is used by one thread at a time; different contexts are independent): upload,
     // decode and the stripe's way to the root are enqueued on that GPU's stream and waited for there, so no GPU waits
@@ -1109,6 +1144,7 @@ static int decode_sharded_impl(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_f
         uint8_t* dst = home;
         if (!(root_is_device && c->device == root->device)) {
             if ((e = grow(c, &c->d_rgb, &c->rgb_cap, sbytes))) return;
+            c->rgb_gen++;
             dst = (uint8_t*)c->d_rgb;
         }
         if (hipMemcpyAsync(c->d_scan, scan + s.b0, len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { e = KPEG_HIP_E_DEVICE; return; }

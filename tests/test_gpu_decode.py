@@ -746,3 +746,28 @@ def test_resident_decode_and_banded_download(ctx, band_rows):
     step = band_rows if band_rows else 200
     step = min(step, 200)
     assert bands == [(r, min(step, 200 - r)) for r in range(0, 200, step)]
+
+
+def test_copies_of_an_image_own_their_pixels(tmp_path):
+    """A copy of the decoder's image taken while the pixels are still on the GPU (lazy source), and the decoder's own image
+    after dumpRawData() has left the source in place: both must still be picture A after the shared context has decoded
+    picture B -- the copy fetches the pixels when it is made, the owner is made to fetch them before the buffer is reused, and
+    a source that outlives its pixels answers "gone" (kpeg_hip_resident_generation) instead of handing out B's."""
+    import ctypes, os
+    import libkpeg_amd as K
+    H = K.load_host()
+    H.kpeg_host_test_image_holders.restype = ctypes.c_size_t
+    H.kpeg_host_test_image_holders.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    w, h = 256, 128
+    a, b = T.synth_jpeg(w, h, seed=5), T.synth_jpeg(w, h, seed=6, sigma=11.0)
+    pa, pb = tmp_path / "a.jpg", tmp_path / "b.jpg"
+    pa.write_bytes(a)
+    pb.write_bytes(b)
+    st, want = T.oracle_decode(a)
+    assert st == T.DECODE_DONE
+    out_copy, out_own = np.zeros(w * h * 3, np.uint8), np.zeros(w * h * 3, np.uint8)
+    n = H.kpeg_host_test_image_holders(str(pa).encode(), str(pb).encode(), out_copy.ctypes.data, out_own.ctypes.data, out_copy.size)
+    assert n == w * h * 3
+    assert np.array_equal(out_copy.reshape(h, w, 3), want), "the copy holds another picture's pixels"
+    assert np.array_equal(out_own.reshape(h, w, 3), want), "the decoder's own image holds another picture's pixels"
+    assert T.sha256(open(tmp_path / "a.ppm", "rb").read()) == T.sha256(T.ppm_bytes(want))
