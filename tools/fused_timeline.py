@@ -42,3 +42,23 @@ for g in list(range(0, nwg, max(1, nwg // 24))) + [nwg - 1]:
 print("last to publish: wg %d at %.2f us; last K2 end %.2f us" % (int(np.argmax(a_pub)), a_pub.max() / 100, a_end.max() / 100))
 print("hand-over: median %.2f us, 90 %% %.2f, max %.2f; of the workgroups behind the last to publish: median %.2f" % (
     np.median(ho) / 100, np.percentile(ho, 90) / 100, ho.max() / 100, np.median(ho[int(np.argmax(a_pub)) + 1:]) / 100 if int(np.argmax(a_pub)) + 1 < nwg else 0))
+# K2's part, every wavefront: loop and epilogue in shader cycles, symbol steps of its busiest lane
+allw = np.arange(nwg * 8)
+loop = (k2[allw, 3].astype(np.int64) - k2[allw, 2].astype(np.int64))
+epi = (k2[allw, 4].astype(np.int64) - k2[allw, 3].astype(np.int64))
+mx = (k2[allw, 6] >> np.uint64(32)).astype(np.int64)
+sm = (k2[allw, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+ok = k2[allw, 2] != 0
+pc = lambda a: " ".join("%7d" % np.percentile(a, q) for q in (0, 10, 50, 90, 99, 100))
+print("K2 per wavefront (cycles; percentiles 0 10 50 90 99 100):")
+print("   loop            %s" % pc(loop[ok]))
+print("   epilogue        %s" % pc(epi[ok]))
+print("   steps, busiest lane %s   mean steps per lane %.1f" % (pc(mx[ok]), sm[ok].sum() / (64.0 * ok.sum())))
+print("   cycles per step of the busiest lane: median %.0f" % np.median(loop[ok] / np.maximum(mx[ok], 1)))
+for name, sel in (("workgroups 0..255", allw < 256 * 8), ("256..511", (allw >= 256 * 8) & (allw < 512 * 8)), ("512..", allw >= 512 * 8)):
+    s2 = ok & sel
+    if s2.any():
+        print("   %-18s loop median %6d  epilogue median %6d  cycles per step %4.0f" % (name, np.median(loop[s2]), np.median(epi[s2]), np.median(loop[s2] / np.maximum(mx[s2], 1))))
+# per workgroup: the slowest wavefront's loop end against wavefront 0's
+wl = loop.reshape(nwg, 8)
+print("   slowest wavefront's loop / wavefront 0's, per workgroup: median %.2f" % np.median(wl.max(1) / np.maximum(wl[:, 0], 1)))
