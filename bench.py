@@ -66,6 +66,28 @@ def synth_jpeg(w, h, y0=0, restart_interval=0, seed=SEED, quality=QUALITY, sigma
     return buf[:n].tobytes()
 
 
+# Natural content beside the synthetic field: the committed photographs (tests/golden: the reference's own lena.jpg and a Pillow-encoded
+# sample photograph), tiled to 7680 x 4352 and re-encoded by the integer-only test encoder (tools/kpeg_synth.c) -- regenerable byte for
+# byte wherever Pillow decodes the source files to the same pixels; tests/golden/make_golden_photos.py pinned their pixels to libKPEG's
+# own decoder (manifest_large.json: "natural_8k").
+PHOTO_CASES = [("lena.jpg", 50), ("lena.jpg", 75), ("nat_china_640x424_q90.jpg", 75), ("nat_china_640x424_q90.jpg", 90)]
+PHOTO_W, PHOTO_H = 7680, 4352
+
+
+def tiled_photo_jpeg(src, quality, w=PHOTO_W, h=PHOTO_H):
+    from PIL import Image
+    im = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", src)).convert("RGB"))
+    big = np.ascontiguousarray(np.tile(im, (h // im.shape[0] + 1, w // im.shape[1] + 1, 1))[:h, :w])
+    S = _synth()
+    S.kpeg_synth_encode_rgb.restype = ctypes.c_size_t
+    S.kpeg_synth_encode_rgb.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]
+    cap = w * h * 4 + 65536
+    buf = np.empty(cap, np.uint8)
+    n = S.kpeg_synth_encode_rgb(big.ctypes.data, w, h, quality, 0, buf.ctypes.data, cap)
+    assert n > 0
+    return buf[:n].tobytes()
+
+
 def pinned_rgb_sha(w, h, world, rank, restart_stripe):
     """SHA-256 of the raw RGB bytes libKPEG's own decoder produces for this rank's part of the workload, if pinned."""
     mf = os.path.join(ROOT, "tests", "golden", "manifest_large.json")
@@ -236,6 +258,8 @@ def main():
     ap.add_argument("--image16k", action="store_true",
                     help="N=1: decode config 5's 16384x16384 restart-interval image on one GPU (the N>1 runs' workload) instead of the 8K headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-photographs", action="store_true",
+                    help="skip the natural-content figure (four committed photographs tiled to 7680x4352; ~15 s of host-side encoding)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dry run on a one-GPU box: gloo backend, every rank on cuda:0 (the driver's runs use RCCL, one GPU per rank)")
@@ -509,6 +533,48 @@ def main():
                                 "ms_per_image": round(qms, 4), "Mpixels_per_s": round(pw * ph / (qms * 1e-3) / 1e6, 1),
                                 "k1_launches_with_work": ctx.timings().get("sync_rounds"), "verified": okp})
 
+    # ---- natural content at the headline's size: the synthetic field is the friendly case (1.04 bits per pixel, re-synchronises after
+    # ~64 bits); photographs carry 1-3 bits per pixel and re-synchronise more slowly.  Four committed photographs tiled to 7680 x 4352,
+    # each verified against libKPEG's own decoder's pixels (tests/golden/make_golden_photos.py); the summary is their geometric mean.
+    photos8k = None
+    if world == 1 and not args.idct_only and not args.no_photographs and args.idct_mode == 0 and (W, H) == (W8K, H8K) and not strong and not args.restart_stripe:
+        try:
+            import hashlib
+            man8 = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest_large.json"))).get("natural_8k", {})
+            cases = []
+            pd_rgb = torch.empty((PHOTO_H, PHOTO_W, 3), dtype=torch.uint8, device="cuda")
+            for (src, q) in PHOTO_CASES:
+                pdata = tiled_photo_jpeg(src, q)
+                g = man8.get("%s_q%d_%dx%d" % (os.path.splitext(src)[0], q, PHOTO_W, PHOTO_H))
+                prc, pframe, pscan = K.host_parse(pdata)
+                assert prc == K.DECODE_DONE, prc
+                pd_scan = torch.from_numpy(np.ascontiguousarray(pscan)).cuda()
+                for _ in range(3):
+                    ctx.decode_stripe_dev(pframe, pd_scan.data_ptr(), pd_scan.numel(), 0, PHOTO_H // 8, pd_rgb.data_ptr())
+                ctx.sync()
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+                for _ in range(20):
+                    ctx.decode_stripe_dev(pframe, pd_scan.data_ptr(), pd_scan.numel(), 0, PHOTO_H // 8, pd_rgb.data_ptr())
+                torch.cuda.synchronize()
+                qms = (time.perf_counter() - q0) / 20 * 1e3
+                ctx.sync()
+                okp = None
+                if g and hashlib.sha256(pdata).hexdigest() == g["jpg_sha256"]:
+                    okp = hashlib.sha256(pd_rgb.cpu().numpy().tobytes()).hexdigest() == g["rgb_sha256"]
+                    if not okp:
+                        raise SystemExit("bench.py: %s q%d tiled to 8K decodes to pixels that differ from the reference's" % (src, q))
+                cases.append({"source": src, "quality": q, "bits_per_pixel": round(len(pscan) * 8 / (PHOTO_W * PHOTO_H), 2), "ms_per_image": round(qms, 4),
+                              "Mpixels_per_s": round(PHOTO_W * PHOTO_H / (qms * 1e-3) / 1e6, 1), "k1_launches_with_work": ctx.timings().get("sync_rounds"),
+                              "verified": okp})
+            gm = float(np.exp(np.mean([np.log(c["Mpixels_per_s"]) for c in cases])))
+            photos8k = {"geomean_Mpixels_per_s": round(gm, 1), "size": "%dx%d" % (PHOTO_W, PHOTO_H), "cases": cases,
+                        "verified": None if any(c["verified"] is None for c in cases) else all(c["verified"] for c in cases),
+                        "what": "committed photographs tiled to the headline's size and re-encoded (tools/kpeg_synth.c); their pixels pinned to libKPEG's own decoder"}
+            del pd_rgb
+        except ImportError:
+            photos8k = {"skipped": "Pillow is not importable here"}
+
     # ---- decode + gather of the stripes to rank 0 (the path's one exchange step), timed apart --------------------
     # Every rank decodes its stripe as two bands of whole MCU rows; a band leaves for rank 0 (point-to-point send over
     # RCCL/xGMI, straight into its rows of the root's image) as soon as it is decoded, while the next band decodes.
@@ -664,6 +730,8 @@ def main():
             out["stress"] = stress
         if photographs:
             out["photographs"] = photographs
+        if photos8k:
+            out["photographs_8k"] = photos8k
         if gather:
             out["gather"] = gather
             out["value_incl_gather"] = round(pixels_per_step / (gather["ms_decode_and_gather"] * 1e-3) / 1e6, 2)

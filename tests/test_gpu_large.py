@@ -65,6 +65,30 @@ def test_photographs_match_the_reference_ppm(ctx, name):
         assert sha(T.ppm_bytes(rgb)) == g["ppm_sha256"], subseq
 
 
+@pytest.mark.parametrize("key", sorted(LARGE.get("natural_8k", {})))
+def test_photographs_tiled_to_8k_match_the_reference(ctx, key):
+    """The natural-content inputs of bench.py's default line (committed photographs tiled to 7680 x 4352, 1.0-3.5 bits per pixel):
+    pixels against libKPEG's own decoder (tests/golden/make_golden_photos.py), with k_sync_write and through the separate
+    launches.  On these the one-kernel path usually hands on (some workgroup's entry assumption fails)."""
+    import sys
+    pytest.importorskip("PIL")
+    sys.path.insert(0, T.ROOT)
+    import bench
+    import libkpeg_amd as K
+    g = LARGE["natural_8k"][key]
+    data = bench.tiled_photo_jpeg(g["source"], g["quality"], g["width"], g["height"])
+    assert sha(data) == g["jpg_sha256"], "the tiled input is no longer reproduced byte for byte"
+    rc, frame, scan = K.host_parse(data)
+    assert rc == K.DECODE_DONE
+    try:
+        for fused in (1, 0):
+            assert ctx.lib.kpeg_hip_debug_set(ctx._h, 9, fused) == 0
+            rgb = ctx.decode_scan(frame, scan)
+            assert sha(rgb.tobytes()) == g["rgb_sha256"], fused
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)
+
+
 def test_batch_of_256_1080p_images(ctx):
     """BASELINE config 4 exactly as bench.py --batch 256 times it: 256 device-resident 1080p images, 32 distinct
     scans (seeds 1234..1265), one call of kpeg_hip_decode_batch_dev.  The first 32 outputs are hashed against the
