@@ -7,29 +7,28 @@
 //
 // Bit-exactness.  The reference evaluates every sample as a 64-term sum accumulated in
 // *float* in (u outer, v inner) order from double products; its rounding
-// cannot be reproduced by a fast transform.  The kernel therefore computes
-//   (1) a fast separable f32 IDCT whose distance to the reference's float result is
-//       bounded rigorously per block (tools/idct_bound.py derives the constant), and
-//   (2) only where the fast value lies within that bound of a rounding boundary (or the G
-//       term is too close to an integer for the f32 colour arithmetic), the reference-order
-//       evaluation itself: such pixels are queued in the tile loop and fixed up in passes,
-//       after their tile has been stored (see k_idct_colour_fast).
+// cannot be reproduced by a fast transform.  So:
+//   (1) k_idct_colour_fast computes a fast separable f32 IDCT whose distance to the reference's float
+//       result is bounded rigorously per block (tools/idct_bound.py derives the constant), and
+//   (2) where the fast value lies within that bound of a rounding boundary (or the G term is too close
+//       to an integer for the f32 colour arithmetic) it only MARKS the pixel in its tile loop and queues the
+//       pixel's row in LDS; fx_flush, called when a wavefront's queue is full and when its tiles are done,
+//       evaluates the marked pixels in the reference's own order and stores their bytes over the fast ones.
 // Blocks with no AC coefficient are exact in (1) by construction.
 //
-// Mapping (no MFMA: byte/short work, not a dense contraction; the kernel is bound by VALU issue,
-// and on gfx950 only add/sub/mul/fma/and/or/mov issue at 1.7 cycles, everything else at 2.7:
-// tools/ubench/valu_rate.hip).
-//   * one wavefront per workgroup, 8 lanes per MCU, 8 MCUs (64x8 pixels) per tile; the grid is the
-//     resident wavefronts, each walks tiles blockIdx.x, + gridDim.x, ...
+// Mapping (no MFMA: byte/short work, not a dense contraction; the kernel is bound by its instruction stream).
+//   * one workgroup of K4_WAVES wavefronts per CU; every wavefront an independent worker that takes tiles of
+//     8 MCUs (64 x 8 pixels) from the workgroup's share through a counter in LDS; 8 lanes per MCU.
 //   * lane j of an 8-lane group loads one 16-byte row of each component block
 //     (rows 0,2,4,6 on lanes 0-3, rows 1,3,5,7 on lanes 4-7): a wavefront's three
-//     global_load_dwordx4 cover 8 MCUs x 384 B = 3 KiB of contiguous coefficients.
+//     global_load_dwordx4 cover 8 MCUs x 384 B = 3 KiB of contiguous coefficients -- or, compact stream, the
+//     tile's records (4 bytes per non-zero AC coefficient) are scattered into an LDS image of the 24 blocks first.
 //   * row pass (over v) in registers: even/odd decomposition, 34 f32 ops per 8 samples;
 //     column pass (over u) across the 8 lanes with DPP: quad broadcasts feed 4-term
 //     even (lanes 0-3) / odd (lanes 4-7) sums, one row_half_mirror FMA combines them.
 //     Lane l ends up with pixel row l of the block: 8 pixels x 3 components.
 //   * colour conversion in f32/int-exact arithmetic (proven ranges), RGB bytes staged in an
-//     LDS tile (8 rows x 768 B, padded rows) and written back with 16-byte coalesced stores.
+//     LDS tile (8 rows x 768 B, padded rows) and written back with 16-byte coalesced nontemporal stores.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -251,18 +250,18 @@ __global__ __launch_bounds__(256) void k_idct_colour_exact_420(const int16_t* __
 #define KPEG_G_DELTA 6.0e-5f
 
 // Range guards folded into the bound: every fast sample satisfies |v| <= A (1 + 2^-20).
-//   A >= KPEG_A_LIM (any component): beyond the range the colour arithmetic's rounding argument is checked for
-//       (|sample| <= 4100, tests/test_tables.py): E = +inf, all the block's samples take the reference-order path.
+//   A >= KPEG_A_LIM (any component): E = +inf, all the block's samples take the reference-order path.  Below it every sample
+//       is an integer of at most 2041 in magnitude once rounded: inside the range the colour arithmetic's rounding argument is
+//       checked for (|sample| <= 4100, tests/test_tables.py) and exact as an f16 (K4's row queue keeps the rounded samples so).
 //   A >= KPEG_A_LIM_CHROMA (chroma block): the samples may leave the range the f32 colour arithmetic is proven
 //       for (|.| < 250): the lowest mantissa bit of E is set (E is first rounded up to an even mantissa, so the
 //       bit never shrinks it) and K4 converts that MCU's pixels with the reference's double arithmetic in-lane.
 //       Saturated colour edges do this in photographs; dense noise does it everywhere.
 #define KPEG_A_LIM_CHROMA 249.0f
-#define KPEG_A_LIM 4000.0f
+#define KPEG_A_LIM 2040.0f
 // The sign bit carries one more fact about the block: set = every non-zero AC coefficient sits at
 // (0,1), (1,0) or (1,1).  Those blocks produce nearly all true ties (equal and opposite (0,1)/(1,0)
-// terms cancel on the diagonal), and their reference-order sum has at most four terms, which the
-// lane that holds the pixel's queue entry evaluates itself in the fix-up pass (exact_corner).
+// terms cancel on the diagonal).  (K4 reads the magnitude only; the sign is kept for tools and tests.)
 __device__ __forceinline__ float block_ebound(float A, int nnz_ac, bool chroma, bool corner_only)
 {
     if (!(A < KPEG_A_LIM)) return __builtin_inff();
@@ -306,7 +305,6 @@ typedef unsigned int __attribute__((ext_vector_type(4), may_alias)) uint4v;  // 
 constexpr int TILE_MCUS = 8;                    // MCUs per wavefront iteration (8 lane groups)
 constexpr int TILE_ROW_BYTES = TILE_MCUS * 24;  // 192
 constexpr int TILE_ROW_STRIDE = 208;            // padded: 13 x 16 bytes, conflict-free b64 writes across rows
-constexpr int QUEUE_CAP = 64;                   // queue entries per wavefront (fix-ups run from QUEUE_FLUSH entries on); pixels beyond go to the overflow list
 #ifndef KPEG_K4_WAVES
 #define KPEG_K4_WAVES 16
 #endif
@@ -522,31 +520,7 @@ __device__ __forceinline__ uint32_t pk_u8(float v, uint32_t sel, uint32_t old)
     return __builtin_amdgcn_cvt_pk_u8_f32(v, sel, old);  // saturating float -> byte `sel` of old
 }
 
-// ---- reference-order evaluation of single samples (the fix-up passes) ---------------------------
-// Value of one sample of a block whose non-zero coefficients all lie in the 2x2 low-frequency corner:
-// MCU::computeIDCT's sum (MCU.cpp:184-198) restricted to the terms (0,0), (0,1), (1,0), (1,1) in that order --
-// the others are zero and leave the float accumulator unchanged, as do zero terms among these four
-// (x + (+-0) == x), so no test is needed.  cos((2x+1)*0*pi/16) == 1.0 exactly.
-//   w0 / w1: the words holding coefficients (0,0),(0,1) / (1,0),(1,1); q..: the four quantisers;
-//   cx1 = cosT[x][1], cy1 = cosT[y][1].  Returns roundl(ic) as a float (the sample minus the level shift).
-// One lane per sample: nearly all unsafe pixels are of this kind (structural ties, see the kernel).
-__device__ __forceinline__ float exact_corner(uint32_t w0, uint32_t w1, uint32_t q00, uint32_t q01, uint32_t q10, uint32_t q11,
-                                              double cx1, double cy1)
-{
-    const float c0 = 0x1.6a09e6p-1f;  // (float)(1/sqrt 2)
-    const int F00 = (int)(short)(w0 & 0xFFFF) * (int)q00, F01 = ((int)w0 >> 16) * (int)q01;
-    const int F10 = (int)(short)(w1 & 0xFFFF) * (int)q10, F11 = ((int)w1 >> 16) * (int)q11;
-    const float fc00 = (c0 * c0) * (float)F00, fc01 = (c0 * 1.0f) * (float)F01, fc10 = (1.0f * c0) * (float)F10,
-                fc11 = (float)F11;
-    float sum = fc00;                                              // (float)(0.0 + fc00 * 1.0 * 1.0)
-    sum = (float)((double)sum + (double)fc01 * cy1);              // ((double)fc01 * 1.0) * cy1
-    sum = (float)((double)sum + (double)fc10 * cx1);              // ((double)fc10 * cx1) * 1.0
-    sum = (float)((double)sum + ((double)fc11 * cx1) * cy1);
-    const float ic = (float)(0.25 * (double)sum);
-    const float t = truncf(ic), fr = ic - t;
-    return t + (fr >= 0.5f ? 1.0f : 0.0f) - (fr <= -0.5f ? 1.0f : 0.0f);  // roundl: half away from zero
-}
-
+// ---- reference-order evaluation of single samples -------------------------------------------------
 // One sample of any block, evaluated by the whole wavefront: lane p owns coefficient position p = u*8+v
 // (row-major = the reference's loop order) and computes its product term; the float accumulation then walks
 // the non-zero lanes in order.  fc: cc * (float)(coefficient * Q) of this lane's position; x, y wave-uniform.
@@ -610,72 +584,346 @@ __device__ __forceinline__ int exact_sample_lane(const uint4* __restrict__ blk, 
     return level_shift((float)(0.25 * (double)sum));
 }
 
-#ifndef KPEG_PUSH_GROUP
-#define KPEG_PUSH_GROUP 4           // pixel columns per unsafe-pixel test, dense layout (measured 1 / 2 / 4: 68.9 / 65.3 / 64.0 us)
-#endif
-#ifndef KPEG_PUSH_GROUP_COMPACT
-#define KPEG_PUSH_GROUP_COMPACT 2   // ... compact stream (69.0 / 68.1 / 71.3 us: four keep too many registers live there)
-#endif
-#ifndef KPEG_K4_STASH_DENSE
-#define KPEG_K4_STASH_DENSE 0   // dense layout: 1 = queue entries carry their blocks' corner words too (six lane shuffles per tile and six
-                                // more VGPRs: measured no gain); 0 = the fix-up pass loads them from the coefficient buffer
-#endif
-#ifndef KPEG_K4_CHROMA2
-#define KPEG_K4_CHROMA2 0
-#endif
-#ifndef KPEG_K4_LUMA4
-#define KPEG_K4_LUMA4 0
-#endif
-#ifndef KPEG_QUEUE_FLUSH
-#define KPEG_QUEUE_FLUSH 32
-#endif
-constexpr int QUEUE_FLUSH = KPEG_QUEUE_FLUSH;   // queued pixels that make a fix-up pass worth its fixed cost
-constexpr int OVER_CAP = TILE_MCUS * 64 - (QUEUE_CAP - QUEUE_FLUSH);   // a tile starts with at least QUEUE_CAP - QUEUE_FLUSH free entries
-constexpr int QUEUE_WORDS = 8;    // per queued pixel: position, 3 rounded samples, 3 keys (>= 0: that component is unsafe), pad
-constexpr int QUEUE_WORDS_COMPACT = 16;   // ... + words 8..13: the 2x2 corner coefficients of the pixel's three blocks (the compact
-                                          // stream has no block to read them from later)
 constexpr int IMG_BYTES = 24 * 128;       // compact path: the tile's 24 blocks rebuilt in LDS, natural order, int16
 
+// ---- the marked pixels, in the reference's own order ----------------------------------------------------------------------
+// K4's tile loop only MARKS the pixels whose fast value cannot be trusted.  A tile that has any (two in five on the 8K workload)
+// appends the pixel rows that hold them to the wavefront's queue in LDS -- a row entry carries all that settling it takes, so
+// that nothing has to be fetched again -- and when the queue may not hold another tile's rows (or the wavefront's tiles are
+// done) fx_flush settles what has gathered, ONE LANE PER ROW, a marked pixel of every row per round: the components the tile
+// loop does not vouch for are evaluated as MCU::computeIDCT has them (MCU.cpp:184-198: float accumulator, double products,
+// u outer, v inner, zero terms leave the accumulator as it is), the others keep the rounded fast value, then performLevelShift
+// and convertYCbCrToRGB (colour_exact), and the pixel's three bytes are stored over what the tile loop wrote.
+// Why a queue across tiles: a marked tile has six marked pixels on average.  Settling them tile by tile runs the whole
+// reference-order code (some 300 instructions, doubles) for six lanes of 64 -- measured 24-27 us of K4's 83 (profiles/r03_d) --
+// whereas a full queue keeps most lanes busy: a few passes in a wavefront's life.
+//   corner-only blocks (the sign of the block's bound; nine in ten: near-ties of chroma blocks, equal and opposite (0,1)/(1,0)
+//     terms that cancel on the diagonal): four terms by the lane itself, from two words of the block (part of the entry);
+//   any other block, compact stream: settled when the row is queued, while the tile's rebuilt blocks stand in LDS
+//     (fx_noncorner) -- the sample's value replaces the fast one in the entry and the entry vouches for it;
+//   any other block, dense layout: by the lane itself in fx_flush, 64 terms in order from the block's rows in memory.
+// Neither function is inlined: they run a few times in a wavefront's life, and their registers are not to be paid for by the
+// tile loop, which has none to spare (56 bytes of spill per lane, an inlined version's, took K4 from 55 to 85 us).  A called
+// function waits for everything the wavefront has in flight (s_waitcnt 0 at its entry): paid a few times, not per tile.
+constexpr int ROWQ_CAP = 64;      // rows a wavefront's queue holds: a tile's worth
+constexpr int ROWQ_WORDS = 20;    // per row: [0, 12) [component][pixel column] the rounded fast sample (minus the level shift) as f16 (exact: a block
+                                  // with finite bound has |sample| <= KPEG_A_LIM < 2048); [12] per component Y Cb Cr and for the G term one byte,
+                                  // bit 7 - i set = pixel column i is vouched for; [13] tile << 6 | lane of the tile loop (MCU of the tile << 3 |
+                                  // pixel row); [14, 20) compact stream: words 0 and 4 of the MCU's three blocks = coefficients (0,0),(0,1) and (1,0),(1,1)
+struct FxArgs {   // what fx_flush needs of IdctParams, by value (a reference to the kernel's arguments would put them on the stack)
+    uint8_t* rgb;
+    uint8_t* const* rgb_table;
+    const int16_t* coef;
+    const float* ebound;
+    uint32_t pitch, tiles_w, tiles_w_magic, tiles_w_shift, mcus_w, ntiles, rows_per_img;
+};
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef __attribute__((address_space(3))) const double lds_cf64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
+// Value of one sample of any block, evaluated by the whole wavefront (exact_sample_wave with its table in LDS address space)
+__device__ __forceinline__ int fx_sample_wave(float fc, lds_cf64* s_cos, int x, int y, bool nz)
+{
+    const int lane = __lane_id();
+    const int u = lane >> 3, v = lane & 7;
+    const double t = ((double)fc * s_cos[x * 8 + u]) * s_cos[y * 8 + v];
+    unsigned long long live = __ballot(nz);
+    float sum = 0.0f;
+    while (live) {
+        const int p = __builtin_ctzll(live);
+        live &= live - 1;
+        const long long tb = __builtin_bit_cast(long long, t);
+        const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)tb, p);
+        const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), p);
+        const double tp = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        sum = (float)((double)sum + tp);
+    }
+    return level_shift((float)(0.25 * (double)sum));
+}
+
+// Compact stream, when a tile's rows have just been queued: the marked samples of blocks that are NOT corner-only, evaluated while
+// the tile's blocks stand rebuilt in LDS (img: [24][64] int16, natural order).  nc: the lane's row's samples concerned, one byte per
+// component, bit 7 - i = pixel column i (0: none); entry: the lane's queue entry.  The value goes into the entry in place of the
+// fast one (exact in f16: a block with a finite bound has |sample| <= KPEG_A_LIM), and the entry then vouches for it -- and no
+// longer for the pixel's G term, so that the pixel stays marked whatever else it has (fx_flush converts every marked pixel with
+// the reference's own colour arithmetic anyway).
+//   fx_noncorner_few: a few samples in the tile (nearly always): the whole wavefront takes them one after the other, lane =
+//     coefficient position.  Inlined: a call would wait for everything the wavefront has in flight, the next tile's coefficients
+//     and the previous tile's pixels -- 22 us of K4 when every tenth tile did (profiles/r03_d).
+//   fx_noncorner_many (a call): many (a cluster of ties): every lane its own, 64 terms in order; and the rows of MCUs that have
+//     a block whose bound is infinite (inf: bit c; its samples may be anything, f16 does not hold them): the lane finishes its
+//     whole pixel row here, every component by the 64-term sum, into the wavefront's finished tile in LDS (`trow`: the lane's 24
+//     bytes of it), which has not been written back yet; the entry then vouches for everything and fx_flush passes it over.
+__device__ __forceinline__ void fx_vouch(lds_u32* entry, uint32_t vouch)
+{
+    // bits [23:0]: samples settled; the same pixels' G bits are cleared
+    if (vouch) entry[12] = (entry[12] | vouch) & ~(((vouch | (vouch >> 8) | (vouch >> 16)) & 0xFFu) << 24);
+}
+
+__device__ __forceinline__ void fx_noncorner_few(lds_u32* entry, lds_cu32* img, lds_cu32* s_qi, lds_cf64* s_cos, uint32_t nc)
+{
+    const uint32_t lane = (uint32_t)__lane_id();
+    lds_u16* const eh = reinterpret_cast<lds_u16*>(entry);
+    const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
+    uint32_t vouch = 0;
+    unsigned long long rows = __ballot(nc != 0);
+    while (rows) {   // wave-uniform
+        const int L = __builtin_ctzll(rows);
+        rows &= rows - 1;
+        uint32_t ncL = (uint32_t)__builtin_amdgcn_readlane((int)nc, L);
+        while (ncL) {
+            const uint32_t b = 31u - (uint32_t)__builtin_clz(ncL);
+            ncL &= ~(1u << b);
+            const uint32_t c = b >> 3, y = 7u - (b & 7u);
+            const uint32_t wv = img[(((uint32_t)L >> 3) * 3u + c) * 32u + (lane >> 1)];
+            const int cf = (lane & 1u) ? ((int)wv >> 16) : (int)(short)(wv & 0xFFFF);
+            const int F = cf * (int)s_qi[(c ? 64 : 0) + lane];   // m_8x8block after MCU.cpp:110-112
+            const int S = fx_sample_wave(ccl * (float)F, s_cos, L & 7, (int)y, F != 0);
+            if ((int)lane == L) {
+                eh[c * 8 + y] = __builtin_bit_cast(uint16_t, (_Float16)(float)(S - 128));
+                vouch |= 1u << b;
+            }
+        }
+    }
+    fx_vouch(entry, vouch);
+}
+
+#ifdef KPEG_FX_MANY_INLINE
+#define KPEG_FX_MANY_ATTR __forceinline__
+#else
+#define KPEG_FX_MANY_ATTR __attribute__((noinline))
+#endif
+__device__ KPEG_FX_MANY_ATTR void fx_noncorner_many(lds_u32* entry, lds_cu32* img, lds_cu32* s_qi, lds_cf64* s_cos, uint32_t nc, uint32_t inf,
+                                                            __attribute__((address_space(3))) uint8_t* trow)
+{
+    const uint32_t lane = (uint32_t)__lane_id();
+    const uint32_t g = lane >> 3, x = lane & 7u;   // MCU of the tile, pixel row
+    const float c0 = 0x1.6a09e6p-1f;
+    lds_cf64* const cx = s_cos + x * 8;
+    // MCU::computeIDCT's sum for sample (x, y) of block c of the lane's MCU, in its order (MCU.cpp:184-198)
+    auto sum64 = [&](uint32_t c, uint32_t y) -> int {
+        lds_cf64* const cy = s_cos + y * 8;
+        const __attribute__((address_space(3))) uint4v* const rows = reinterpret_cast<const __attribute__((address_space(3))) uint4v*>(img + (g * 3u + c) * 32u);
+        lds_cu32* const qi = s_qi + (c ? 64 : 0);
+        float sum = 0.0f;
+#pragma unroll 1
+        for (int uu = 0; uu < 8; ++uu) {
+            const uint4v d = rows[uu];
+            if ((d.x | d.y | d.z | d.w) == 0u) continue;   // (quantised blocks are mostly empty rows; a zero term leaves the float accumulator unchanged)
+            const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+            const double cxu = cx[uu];
+            const float cu = uu == 0 ? c0 : 1.0f;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int cf = (v & 1) ? ((int)w[v >> 1] >> 16) : (int)(short)(w[v >> 1] & 0xFFFF);
+                if (cf != 0) {
+                    const int F = cf * (int)qi[uu * 8 + v];                     // m_8x8block after MCU.cpp:110-112
+                    const float fc = (cu * (v == 0 ? c0 : 1.0f)) * (float)F;    // Cf[u] * Cf[v] in float, float multiply (MCU.cpp:189-192)
+                    const double t = ((double)fc * cxu) * cy[v];
+                    sum = (float)((double)sum + t);
+                }
+            }
+        }
+        return level_shift((float)(0.25 * (double)sum));
+    };
+    if (__ballot(inf != 0)) {   // wave-uniform; hostile or broken streams
+        if (inf) {
+#pragma unroll 1
+            for (uint32_t y = 0; y < 8; ++y) {
+                int S[3];
+#pragma unroll 1
+                for (uint32_t c = 0; c < 3; ++c) S[c] = sum64(c, y);
+                const uint32_t px = colour_exact(S[0], S[1], S[2]);
+                trow[y * 3] = (uint8_t)px, trow[y * 3 + 1] = (uint8_t)(px >> 8), trow[y * 3 + 2] = (uint8_t)(px >> 16);
+            }
+            entry[12] = 0xFFFFFFFFu;
+            nc = 0;
+        }
+    }
+    lds_u16* const eh = reinterpret_cast<lds_u16*>(entry);
+    uint32_t vouch = 0, mine = nc;
+    while (__ballot(mine != 0)) {   // wave-uniform
+        if (mine) {
+            const uint32_t b = 31u - (uint32_t)__builtin_clz(mine);
+            mine &= ~(1u << b);
+            const uint32_t c = b >> 3, y = 7u - (b & 7u);
+            eh[c * 8 + y] = __builtin_bit_cast(uint16_t, (_Float16)(float)(sum64(c, y) - 128));
+            vouch |= 1u << b;
+        }
+    }
+    fx_vouch(entry, vouch);
+}
+
+// q: the wavefront's queue, nrows entries; s_qi: [2][64] quantisers, natural order.
+template <bool COMPACT>
+__device__ __attribute__((noinline)) void fx_flush(FxArgs a, lds_cu32* q, uint32_t nrows, lds_cu32* s_qi, lds_cf64* s_cos)
+{
+    const uint32_t lane = (uint32_t)__lane_id();
+    const bool have = lane < nrows;
+    const float c0 = 0x1.6a09e6p-1f;
+    // this lane's row
+    uint32_t hs[12], keys = 0xFFFFFFFFu, where = 0, cw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    {
+        lds_cu32* e = q + lane * ROWQ_WORDS;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) hs[k] = have ? e[k] : 0u;
+        if (have) {
+            keys = e[12], where = e[13];
+            if constexpr (COMPACT) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) cw[k] = e[14 + k];
+            }
+        }
+    }
+    const uint32_t tile = min(where >> 6, a.ntiles - 1), Lt = where & 63u;
+    const uint32_t g = Lt >> 3, x = Lt & 7u;   // MCU of the tile, pixel row
+    const uint32_t trow = a.tiles_w == 1 ? tile : (__umulhi(tile, a.tiles_w_magic) >> a.tiles_w_shift), tcol = tile - trow * a.tiles_w;
+    const uint32_t m0 = tcol * TILE_MCUS;
+    const size_t mcu = (size_t)trow * a.mcus_w + m0 + g;
+    uint32_t todo = have ? ~(keys & (keys >> 8) & (keys >> 16) & (keys >> 24)) & 0xFFu : 0u;   // bit 7 - i: pixel column i is marked
+    // dense layout: which blocks are corner-only (the bounds' signs), and those blocks' two words
+    uint32_t crn = 7u;   // compact stream: what is still unsafe in an entry is corner-only (fx_noncorner has settled the rest)
+    if constexpr (!COMPACT) {
+        if (todo) {
+            struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+            const F3 eb = *reinterpret_cast<const F3*>(a.ebound + mcu * 3);
+            crn = (__float_as_int(eb.a) < 0 ? 1u : 0u) | (__float_as_int(eb.b) < 0 ? 2u : 0u) | (__float_as_int(eb.c) < 0 ? 4u : 0u);
+            const uint32_t* c32 = reinterpret_cast<const uint32_t*>(a.coef) + mcu * 96;   // block c at + 32 c words
+            cw[0] = c32[0], cw[1] = c32[4], cw[2] = c32[32], cw[3] = c32[36], cw[4] = c32[64], cw[5] = c32[68];
+        }
+    }
+    // the pixel's bytes in the picture
+    size_t rowoff;
+    {
+        size_t off;
+        if (a.rgb_table) {
+            const uint32_t img = trow / a.rows_per_img;
+            off = (todo ? (size_t)(reinterpret_cast<uintptr_t>(a.rgb_table[img]) - reinterpret_cast<uintptr_t>(a.rgb)) : 0) + (size_t)(trow - img * a.rows_per_img) * 8 * a.pitch;
+        } else {
+            off = (size_t)trow * 8 * a.pitch;
+        }
+        rowoff = off + (size_t)x * a.pitch + (size_t)(m0 + g) * 24;
+    }
+    lds_cf64* const cx = s_cos + x * 8;
+    // a pixel of every row per round
+    while (__ballot(todo != 0)) {   // wave-uniform
+        const bool act = todo != 0;
+        const uint32_t bit = act ? 31u - (uint32_t)__builtin_clz(todo) : 7u;   // highest marked bit first: pixel column 7 - bit
+        todo &= ~(1u << bit);
+        const uint32_t y = 7u - bit;
+        lds_cf64* const cy = s_cos + y * 8;
+        // the pixel's rounded fast samples: half y & 1 of word y >> 1 of every component
+        int S[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t w = hs[c * 4];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) w = (y >> 1) == (uint32_t)k ? hs[c * 4 + k] : w;
+            const uint16_t hb = (uint16_t)((y & 1u) ? w >> 16 : w & 0xFFFFu);
+            S[c] = (int)(float)__builtin_bit_cast(_Float16, hb) + 128;
+        }
+        const uint32_t need = !act ? 0u : ((((keys >> bit) & 1u) ? 0u : 1u) | (((keys >> (8 + bit)) & 1u) ? 0u : 2u) | (((keys >> (16 + bit)) & 1u) ? 0u : 4u));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (!(need & (1u << c))) continue;
+            lds_cu32* qi = s_qi + (c ? 64 : 0);
+            if (COMPACT || (crn & (1u << c))) {
+                // MCU::computeIDCT's sum (MCU.cpp:184-198) for a block that has nothing outside (0,0), (0,1), (1,0), (1,1), in its order; a
+                // zero term leaves the float accumulator as it is (x + (+-0) == x), so none needs a test.  cos((2x+1) 0 pi/16) == 1.0 exactly.
+                const uint32_t wa = cw[2 * c], wb = cw[2 * c + 1];
+                const float fc00 = (c0 * c0) * (float)((int)(short)(wa & 0xFFFF) * (int)qi[0]), fc01 = (c0 * 1.0f) * (float)(((int)wa >> 16) * (int)qi[1]),
+                            fc10 = (1.0f * c0) * (float)((int)(short)(wb & 0xFFFF) * (int)qi[8]), fc11 = (float)(((int)wb >> 16) * (int)qi[9]);
+                float sum = fc00;
+                sum = (float)((double)sum + (double)fc01 * cy[1]);
+                sum = (float)((double)sum + (double)fc10 * cx[1]);
+                sum = (float)((double)sum + ((double)fc11 * cx[1]) * cy[1]);
+                S[c] = level_shift((float)(0.25 * (double)sum));
+            } else {
+                // the 64-term sum in the reference's order, zero coefficients skipped (they leave the float accumulator unchanged)
+                const uint4* blk = reinterpret_cast<const uint4*>(a.coef) + (mcu * 3 + c) * 8;
+                float sum = 0.0f;
+                for (int uu = 0; uu < 8; ++uu) {
+                    const uint4 d = blk[uu];
+                    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+                    const double cxu = cx[uu];
+                    const float cu = uu == 0 ? c0 : 1.0f;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const int cf = (v & 1) ? ((int)w[v >> 1] >> 16) : (int)(short)(w[v >> 1] & 0xFFFF);
+                        if (cf != 0) {
+                            const int F = cf * (int)qi[uu * 8 + v];                     // m_8x8block after MCU.cpp:110-112
+                            const float fc = (cu * (v == 0 ? c0 : 1.0f)) * (float)F;    // Cf[u] * Cf[v] in float, float multiply (MCU.cpp:189-192)
+                            const double t = ((double)fc * cxu) * cy[v];
+                            sum = (float)((double)sum + t);
+                        }
+                    }
+                }
+                S[c] = level_shift((float)(0.25 * (double)sum));
+            }
+        }
+        if (act) {
+            const uint32_t px = colour_exact(S[0], S[1], S[2]);
+            uint8_t* o = a.rgb + rowoff + y * 3;
+            o[0] = (uint8_t)px;
+            o[1] = (uint8_t)(px >> 8);
+            o[2] = (uint8_t)(px >> 16);
+        }
+    }
+}
+
 #ifdef KPEG_K4_STAMP
-__device__ unsigned long long g_k4_stamp[8192 * 4];
+__device__ unsigned long long g_k4_stamp[8192 * 8];
 #endif
 // One workgroup of K4_WAVES wavefronts per CU; every wavefront is an independent worker on tiles of 8 MCUs (64 x 8
-// pixels), no barrier after the start-up.  The workgroup owns a contiguous range of tiles and hands them out through a
-// counter in LDS: on a SIMD the oldest wavefront gets the issue slots first (age arbitration), so with a static split the
-// wavefronts of one SIMD finished one after the other -- first 38 us, last 54-66 us, the SIMD two-thirds idle at the end
-// (profiles/r02: per-wavefront stamps) -- whereas wavefronts that take tiles as they go all finish together.
+// pixels), no barrier after the start-up.  The workgroup owns a fixed share of the tiles (chunks dealt round-robin, see
+// KPEG_K4_CHUNK) and hands them out through a counter in LDS: on a SIMD the oldest wavefront gets the issue slots first (age
+// arbitration), so with a static split the wavefronts of one SIMD finished one after the other -- first 38 us, last 54-66 us,
+// the SIMD two-thirds idle at the end (profiles/r02: per-wavefront stamps) -- whereas wavefronts that take tiles as they go
+// finish within a tile's time of each other.
 //
-// Pixels whose fast value cannot be trusted (within the block's bound of a rounding boundary, or a G term too
-// close to an integer) are only *noted* in the tile loop: their position goes to a small queue in LDS.  Once the
-// tiles they belong to have been written out, a fix-up pass evaluates them in the reference's own order, one lane
-// per (pixel, component), and patches the three bytes in global memory.  Handling them where they are found -- a few
-// lanes of a wavefront, several times per tile -- cost 37 % of the kernel's time (profiles/r01_g: 0.103 -> 0.065 ms with
-// the handling compiled out).
+// Pixels whose fast value cannot be trusted (within the block's bound of a rounding boundary, or a G term too close to an
+// integer) are only MARKED in the pixel loop: every lane shifts the signs of its pixels' four keys into four bytes (one
+// v_alignbit each, in place of the ANDs that used to merge them: no test, no branch) and packs the rounded samples as f16
+// pairs.  Behind the loop ONE wave-uniform test: a tile that has marked pixels (two in five) appends the rows that hold them to
+// the wavefront's queue in LDS, 80 bytes a row, at ranks counted from the test's own ballot; samples of blocks that are not
+// corner-only are settled there and then, while the tile's blocks stand (fx_noncorner_*); fx_flush settles a full queue.
+// Rounds 1 and 2 tested every group of two or four pixel columns where they were made and queued single pixels from inside
+// the loop: a scalar branch on a vector compare per group, the ballots and the pushes were 10-13 of the kernel's 69 us
+// (profiles/r02_h).  What the pieces cost now (8K workload, profiles/r03_d): the tile loop with its marks
+// and the queue 55.6 us, fx_flush 6, the non-corner samples 6 -- a wavefront spends 1.1 + 1.6 us of its 50 in them, but the
+// kernel is bound by its instruction stream, and what one wavefront issues the other three of its SIMD wait for.
+#ifdef KPEG_K4_WPE
+#define KPEG_K4_OCC __attribute__((amdgpu_waves_per_eu(KPEG_K4_WPE, KPEG_K4_WPE)))   // experiments: several smaller workgroups per CU
+#else
+#define KPEG_K4_OCC
+#endif
 template <bool COMPACT>
-__global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, QTables qt)
+__global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(IdctParams p, QTables qt)
 {
-    constexpr int QW = (COMPACT || KPEG_K4_STASH_DENSE) ? QUEUE_WORDS_COMPACT : QUEUE_WORDS;   // entries that stash the blocks' corner words are twice as long
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_all[K4_WAVES][8 * TILE_ROW_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_queue_all[K4_WAVES][QUEUE_CAP * QW];
     __shared__ __attribute__((aligned(16))) uint32_t s_img_all[COMPACT ? K4_WAVES : 1][IMG_BYTES / 4];
-    __shared__ uint16_t s_over_all[K4_WAVES][OVER_CAP];   // unsafe pixels a tile has beyond the queue's room: bits [11:0] of the position word (the
-                                            // fix-up pass that takes them runs before the next tile: the tile is known)
     __shared__ __attribute__((aligned(16))) float s_m[2][64];     // AC input scales, natural order
-    __shared__ __attribute__((aligned(16))) uint32_t s_qi[2][64]; // quantisers (exact dequantisation in the fix-up pass)
-    __shared__ double s_cos[64];
     __shared__ uint32_t s_next;       // next tile of this workgroup's range to hand out
-    __shared__ uint32_t s_wg[2];      // [0] wavefronts of this workgroup that are done, [1] unsafe pixels they counted
+    __shared__ __attribute__((aligned(16))) uint32_t s_rowq_all[K4_WAVES][ROWQ_CAP * ROWQ_WORDS];   // the wavefronts' queues of pixel rows that have a marked pixel
+    __shared__ __attribute__((aligned(16))) uint32_t s_qi[2 * 64];   // quantisers, natural order
+    __shared__ double s_cos[64];
+    __shared__ uint32_t s_wg[2];      // [0] wavefronts of this workgroup that are done, [1] pixels they settled
 
 #ifdef KPEG_K4_STAMP
     // diagnostic build only (tools/k4_clock.py): the shader clock this kernel runs at = d(s_memtime) / d(s_memrealtime) x 100 MHz
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_flush = 0, stamp_nc = 0, stamp_nflush = 0, stamp_nnc = 0;   // shader cycles in fx_flush / the non-corner block, and how often
+#define KPEG_STAMP_BEGIN const unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#define KPEG_STAMP_END(acc, n) acc += __builtin_amdgcn_s_memtime() - stamp_t, n += 1;
+#else
+#define KPEG_STAMP_BEGIN
+#define KPEG_STAMP_END(acc, n)
 #endif
     const int tid = threadIdx.x & 63;   // lane of the wavefront
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint8_t* const s_tile = s_tile_all[wave];
-    uint32_t* const s_queue = s_queue_all[wave];
     uint32_t* const s_img = s_img_all[COMPACT ? wave : 0];
-    uint16_t* const s_over = s_over_all[wave];
     const int lane8 = tid & 7;          // lane within the MCU group = output pixel row
     const int grp = tid >> 3;           // MCU within the tile, 0..7
     const int u = lane8 < 4 ? 2 * lane8 : 2 * (lane8 - 4) + 1;  // coefficient row this lane loads
@@ -683,17 +931,29 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
     if (threadIdx.x < 128) {
         const int t = threadIdx.x >> 6, k = threadIdx.x & 63;
         s_m[t][k] = 0.25f * cc_of(k >> 3, k & 7) * (float)qt.q[t][k];
-        s_qi[t][k] = qt.q[t][k];
-    } else if (threadIdx.x < 192) {
-        s_cos[tid] = c_cos[tid];
-    } else if (threadIdx.x == 192) {
+        s_qi[t * 64 + k] = qt.q[t][k];
+    } else if (threadIdx.x == 128) {
         s_next = 0;
         s_wg[0] = 0;
         s_wg[1] = 0;
+    } else if (threadIdx.x >= 192 && threadIdx.x < 256) {
+        s_cos[tid] = c_cos[tid];
     }
-    // this workgroup's tiles: [wg_tile0, wg_tile0 + wg_ntiles)
-    const uint32_t wg_tile0 = (uint32_t)(((unsigned long long)p.ntiles * blockIdx.x) / gridDim.x);
-    const uint32_t wg_ntiles = (uint32_t)(((unsigned long long)p.ntiles * (blockIdx.x + 1)) / gridDim.x) - wg_tile0;
+    // This workgroup's tiles: chunks of KPEG_K4_CHUNK consecutive tiles, dealt round-robin to the workgroups -- tile number k of the
+    // workgroup is tile ((k / CHUNK) * workgroups + blockIdx) * CHUNK + k % CHUNK.  A contiguous range per workgroup (rounds 1 and 2)
+    // leaves the workgroups that own a patch of marked pixels (they come in clusters: a textured region, a ramp whose blocks tie
+    // on their diagonals) working after the others are done; dealt out, a patch is everybody's.
+#ifndef KPEG_K4_CHUNK
+#define KPEG_K4_CHUNK 8
+#endif
+    constexpr uint32_t CHUNK = KPEG_K4_CHUNK;
+    uint32_t wg_ntiles;
+    {
+        const uint32_t round = gridDim.x * CHUNK, full = p.ntiles / round, rem = p.ntiles - full * round;
+        const uint32_t mine = rem > blockIdx.x * CHUNK ? min(rem - blockIdx.x * CHUNK, CHUNK) : 0u;
+        wg_ntiles = full * CHUNK + mine;
+    }
+    auto tile_of = [&](uint32_t k) -> uint32_t { return ((k / CHUNK) * gridDim.x + blockIdx.x) * CHUNK + k % CHUNK; };
     LaneConst lc;
     lc.q0[0] = (float)qt.q[0][u * 8];
     lc.q0[1] = (float)qt.q[1][u * 8];
@@ -715,6 +975,23 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
     // odd lane (pixel row 7-x): E_x - O_x = mirror(E_x) + own(-O_x) -> s = +1.
     lc.s = lane8 < 4 ? -1.0f : 1.0f;
     __syncthreads();   // the tables and the tile counter stand (the only workgroup barrier)
+    uint32_t fx_lane = 0;      // marked pixels of this lane so far
+    uint32_t* const s_rowq = s_rowq_all[wave];
+    uint32_t qcount = 0;       // rows in the queue (wave-uniform)
+    auto flush_rows = [&]() {
+        KPEG_STAMP_BEGIN
+        // the queued rows' tiles have been handed to the memory system (write_back); their stores must have been performed before bytes
+        // of theirs are patched
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const FxArgs fa = {p.rgb, p.rgb_table, p.coef, p.ebound, p.pitch, p.tiles_w, p.tiles_w_magic, p.tiles_w_shift, p.mcus_w, p.ntiles, p.rows_per_img};
+#ifndef KPEG_FX_NO_FLUSH
+        fx_flush<COMPACT>(fa, (lds_cu32*)s_rowq, qcount, (lds_cu32*)s_qi, (lds_cf64*)s_cos);
+#endif
+        qcount = 0;
+        KPEG_STAMP_END(stamp_flush, stamp_nflush)
+    };
     // takes the next tile of the workgroup's range: the value is asked for one tile ahead, so the LDS round trip is not waited for
     auto take_tile = [&]() -> uint32_t {
         uint32_t t = 0;
@@ -726,8 +1003,9 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
     // (8 x 12 = 96 chunks: lanes 0..47 store chunk k of row r and of row r + 4; two registers per lane hold it all).
     // It is issued one iteration late, ahead of the next loads, so that waiting for a tile's
     // coefficients never waits for the stores that follow them in issue order.
-    const uint32_t wb_r = (uint32_t)tid / 12u, wb_k = (uint32_t)tid - wb_r * 12u;
-    const uint32_t wb_lds = wb_r * TILE_ROW_STRIDE + wb_k * 16, wb_g = wb_r * p.pitch + wb_k * 16;
+    // (the lane's two offsets are worked out anew for every tile, from a lane number the compiler cannot see through: kept across the
+    // loop they are two more registers than there are, and the spilled one came back through a scratch load whose wait was a wait for
+    // the next tile's coefficients -- 20 us of K4, profiles/r03_d)
     const bool pitch16 = ((reinterpret_cast<uintptr_t>(p.rgb) | p.pitch) & 15) == 0;
     // Where a tile's pixels go, as an offset from the kernel argument p.rgb -- also in table mode: a pointer
     // loaded from memory has no known address space, its stores would be flat_store, and LDS waits wait for
@@ -751,8 +1029,10 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
     auto write_back = [&](size_t off, uint32_t nm) {
         // the lane's share of a tile stays a 32-bit offset added to a scalar base (global_store with an SGPR base):
         // left alone, the compiler adds p.rgb to every lane offset ahead of the loop and keeps 64-bit addresses in VGPRs
-        uint32_t oA = wb_g;
-        asm volatile("" : "+v"(oA));
+        uint32_t wl = (uint32_t)tid;
+        asm volatile("" : "+v"(wl));
+        const uint32_t wb_r = wl / 12u, wb_k = wl - wb_r * 12u;
+        const uint32_t wb_lds = wb_r * TILE_ROW_STRIDE + wb_k * 16, oA = wb_r * p.pitch + wb_k * 16;
         uint8_t* base = p.rgb + off;
         if (nm == TILE_MCUS && pitch16) {
             if (tid < 48) {
@@ -776,268 +1056,12 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         }
     };
 
-    uint32_t dbg_count = 0;   // experiments (KPEG_COUNT_*): reported in place of the unsafe-pixel count
-
-    // Fix-up passes.  A queue entry is a pixel of one of this wavefront's tiles:
-    //   word 0: [2:0] MCU within the tile, [5:3] pixel row, [8:6] pixel column, [11:9] component blocks that are
-    //           corner-only (the sign of their bound), [31:12] the tile's number k inside the workgroup's range (tile = wg_tile0 + k);
-    //   words 1..3: the three rounded fast samples (minus the level shift); words 4..6: their keys (>= 0: unsafe).
-    // nq queued entries, then nover pixels of the overflow list: position words only (a tile with more unsafe pixels
-    // than the queue had room for: clusters of ties, adversarial input), all components to be evaluated.  One lane per entry.  Unsafe components of corner-only blocks are settled by the lane itself
-    // with the four-term sum; the others (a few per wavefront) by the whole wavefront, one after the other; the lane
-    // then converts and stores its pixel.
-    // The tiles concerned have been written out by this wavefront before.
-    auto run_fixups = [&](uint32_t nq, uint32_t nover, uint32_t over_k) {
-        uint32_t lane = (uint32_t)tid;
-        asm volatile("" : "+v"(lane));   // nothing of a fix-up pass is to be computed ahead of the tile loop and kept in registers
-        const uint32_t total = nq + nover;
-        const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
-        for (uint32_t base = 0; base < total; base += 64) {
-            const uint32_t e = base + lane;
-            const bool valid = e < total;
-            uint32_t pos = 0;
-            float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, f0 = -1.0f, f1 = -1.0f, f2 = -1.0f;
-            if (valid) {
-                if (e < nq) {
-                    const uint4v a = *reinterpret_cast<const uint4v*>(s_queue + e * QW);
-                    const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 4);
-                    pos = a.x;
-                    r0 = __uint_as_float(a.y), r1 = __uint_as_float(a.z), r2 = __uint_as_float(a.w);
-                    f0 = __uint_as_float(b.x), f1 = __uint_as_float(b.y), f2 = __uint_as_float(b.z);
-                } else {
-                    pos = (uint32_t)s_over[e - nq] | (over_k << 12);
-                    f0 = f1 = f2 = 1.0f;
-                }
-            }
-            const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
-            const uint32_t tile = wg_tile0 + (pos >> 12);
-            const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
-            const uint32_t m0 = tcol * TILE_MCUS;
-            const uint32_t mcu = trow * p.mcus_w + m0 + g;
-            const bool need0 = f0 >= 0.0f, need1 = f1 >= 0.0f, need2 = f2 >= 0.0f;
-            // corner-only blocks: the two words such a block consists of
-#ifdef KPEG_FX_SKIP_CORNER
-            const bool cn0 = false, cn1 = false, cn2 = false;
-#else
-            // A queue entry carries the corner words of its three blocks (stashed when it was pushed: no load, no memory latency
-            // in this pass); an overflow-list pixel has none: dense layout -> two 4-byte loads per block, compact stream -> the
-            // general way (from the tile's image).
-            const bool from_queue = valid && e < nq && (COMPACT || KPEG_K4_STASH_DENSE);
-            const bool stashed = !COMPACT || from_queue;
-            const bool cn0 = need0 && (pos & (1u << 9)) && stashed, cn1 = need1 && (pos & (1u << 10)) && stashed, cn2 = need2 && (pos & (1u << 11)) && stashed;
-#endif
-            uint32_t w00 = 0, w01 = 0, w10 = 0, w11 = 0, w20 = 0, w21 = 0;
-            if (from_queue) {
-                const uint4v cw = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 8);
-                const uint2 cw2 = *reinterpret_cast<const uint2*>(s_queue + e * QW + 12);
-                w00 = cw.x, w01 = cw.y, w10 = cw.z, w11 = cw.w, w20 = cw2.x, w21 = cw2.y;
-            } else if constexpr (!COMPACT) {
-                const uint32_t* c32 = reinterpret_cast<const uint32_t*>(p.coef) + (size_t)mcu * 96;
-                if (cn0) w00 = c32[0], w01 = c32[4];
-                if (cn1) w10 = c32[32], w11 = c32[36];
-                if (cn2) w20 = c32[64], w21 = c32[68];
-            }
-            // the others: wave-uniform lists of (lane, component)
-            unsigned long long g0 = __ballot(need0 && !cn0), g1 = __ballot(need1 && !cn1), g2 = __ballot(need2 && !cn2);
-#ifdef KPEG_FX_SKIP_COOP
-            g0 = g1 = g2 = 0;
-#endif
-            auto pop = [](unsigned long long& m0_, unsigned long long& m1_, unsigned long long& m2_, uint32_t& c, uint32_t& L) {
-                unsigned long long& mm = m0_ ? m0_ : (m1_ ? m1_ : m2_);
-                c = m0_ ? 0u : (m1_ ? 1u : 2u);
-                L = (uint32_t)__builtin_ctzll(mm);
-                mm &= mm - 1;
-            };
-            // The coefficient at position `lane` of block c of MCU mcuL (wave-uniform arguments), for the samples the whole
-            // wavefront evaluates.  Dense layout: one coalesced 128-byte load.  Compact stream: from the tile's image in LDS --
-            // only pixels of the tile that was computed last get here (the overflow list, settled before the next tile;
-            // queued pixels had their non-corner samples settled by resolve_noncorner while their tile's image stood).
-            auto fetch_coef = [&](uint32_t mcuL, uint32_t c, int) -> int {
-                if constexpr (!COMPACT) {
-                    return p.coef[((size_t)mcuL * 3 + c) * 64 + lane];
-                } else {
-                    const uint16_t* img16 = reinterpret_cast<const uint16_t*>(s_img);
-                    return (int)(int16_t)img16[((mcuL & (TILE_MCUS - 1)) * 3 + c) * 64 + lane];
-                }
-            };
-#ifndef KPEG_COOP_BATCH
-#define KPEG_COOP_BATCH 2
-#endif
-            constexpr int BATCH = KPEG_COOP_BATCH;
-            const bool many = __popcll(g0) + __popcll(g1) + __popcll(g2) > BATCH;   // wave-uniform
-#if defined(KPEG_COUNT_COOP)
-            dbg_count += __popcll(g0) + __popcll(g1) + __popcll(g2);
-#elif defined(KPEG_COUNT_MANY)
-            dbg_count += many ? 1u : 0u;
-#elif defined(KPEG_COUNT_FLUSH)
-            dbg_count += 1u;
-#elif defined(KPEG_COUNT_CORNER)
-            dbg_count += __popcll(__ballot(cn0)) + __popcll(__ballot(cn1)) + __popcll(__ballot(cn2));
-#endif
-            // a batch of those: one coalesced 128-byte load per sample, all in flight together with the corner words
-            // (one memory latency per pass -- at the end of a wavefront's life nothing hides it)
-            int cf[BATCH];
-            unsigned long long a0 = g0, a1 = g1, a2 = g2;
-            if (!many) {
-#pragma unroll
-                for (int k = 0; k < BATCH; ++k) {
-                    cf[k] = 0;
-                    if (a0 | a1 | a2) {
-                        uint32_t c, L;
-                        pop(a0, a1, a2, c, L);
-                        const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
-                        cf[k] = fetch_coef(mcuL, c, k);
-                    }
-                }
-            }
-            const double cx1 = s_cos[x * 8 + 1], cy1 = s_cos[y * 8 + 1];
-            if (cn0) r0 = exact_corner(w00, w01, s_qi[0][0], s_qi[0][1], s_qi[0][8], s_qi[0][9], cx1, cy1);
-            if (cn1) r1 = exact_corner(w10, w11, s_qi[1][0], s_qi[1][1], s_qi[1][8], s_qi[1][9], cx1, cy1);
-            if (cn2) r2 = exact_corner(w20, w21, s_qi[1][0], s_qi[1][1], s_qi[1][8], s_qi[1][9], cx1, cy1);
-            if (many) {
-                // a tile evaluated as a whole, a cluster of unsafe pixels: every lane its own samples, component by component
-#pragma unroll 1
-                for (int c = 0; c < 3; ++c) {
-                    const bool nd = c == 0 ? (need0 && !cn0) : (c == 1 ? (need1 && !cn1) : (need2 && !cn2));
-                    if (__ballot(nd) == 0) continue;
-                    int S = 128;
-                    if (nd) {
-                        const uint4* blk = COMPACT ? reinterpret_cast<const uint4*>(s_img) + ((mcu & (TILE_MCUS - 1)) * 3 + c) * 8
-                                                   : reinterpret_cast<const uint4*>(p.coef) + ((size_t)mcu * 3 + c) * 8;
-                        S = exact_sample_lane(blk, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
-                    }
-                    const float rv = (float)(S - 128);
-                    if (nd) {
-                        if (c == 0) r0 = rv;
-                        else if (c == 1) r1 = rv;
-                        else r2 = rv;
-                    }
-                }
-            } else {
-                // by the whole wavefront, one sample after the other, lane = coefficient position
-                for (;;) {
-#pragma unroll
-                    for (int k = 0; k < BATCH; ++k) {
-                        if (g0 | g1 | g2) {   // wave-uniform
-                            uint32_t c, L;
-                            pop(g0, g1, g2, c, L);
-                            const int xL = __builtin_amdgcn_readlane((int)x, (int)L), yL = __builtin_amdgcn_readlane((int)y, (int)L);
-                            const int F = cf[k] * (int)s_qi[c ? 1 : 0][lane];          // m_8x8block after MCU.cpp:110-112
-                            const int S = exact_sample_wave(ccl * (float)F, s_cos, xL, yL, F != 0);
-                            const float rv = (float)(S - 128);
-                            if (lane == L) {
-                                if (c == 0) r0 = rv;
-                                else if (c == 1) r1 = rv;
-                                else r2 = rv;
-                            }
-                        }
-                    }
-                    if (!(g0 | g1 | g2)) break;
-                    // the next batch (clusters only)
-#pragma unroll
-                    for (int k = 0; k < BATCH; ++k) {
-                        cf[k] = 0;
-                        if (a0 | a1 | a2) {
-                            uint32_t c, L;
-                            pop(a0, a1, a2, c, L);
-                            const uint32_t mcuL = (uint32_t)__builtin_amdgcn_readlane((int)mcu, (int)L);
-                            cf[k] = fetch_coef(mcuL, c, k);
-                        }
-                    }
-                }
-            }
-            // the tile's own stores (issued before this pass's loads) must have been performed before bytes of theirs are patched
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (valid) {
-                const uint32_t px = colour_exact((int)r0 + 128, (int)r1 + 128, (int)r2 + 128);
-                size_t off;
-                if (p.rgb_table) {
-                    const uint32_t img = trow / p.rows_per_img;
-                    off = (size_t)(reinterpret_cast<uintptr_t>(p.rgb_table[img]) - reinterpret_cast<uintptr_t>(p.rgb)) +
-                          (size_t)(trow - img * p.rows_per_img) * 8 * p.pitch;
-                } else {
-                    off = (size_t)trow * 8 * p.pitch;
-                }
-                uint8_t* o = p.rgb + off + (size_t)x * p.pitch + (size_t)(m0 + g) * 24 + y * 3;
-                o[0] = (uint8_t)px;
-                o[1] = (uint8_t)(px >> 8);
-                o[2] = (uint8_t)(px >> 16);
-            }
-        }
-    };
-
-    // Compact stream only.  The queue entries [first, last) were pushed by the tile whose image stands in LDS; those of
-    // them with an unsafe sample in a block that is NOT corner-only get that sample evaluated now, in the reference's order,
-    // from the image (the whole wavefront per sample, lane = coefficient position; lane-parallel when there are many) and
-    // written back into the entry with its key cleared: later the compact stream offers no block to read.  What remains
-    // for the deferred pass: corner-only samples (from the stashed words), the colour conversion and the three bytes.
-    auto resolve_noncorner = [&](uint32_t first, uint32_t last) {
-        uint32_t lane = (uint32_t)tid;
-        asm volatile("" : "+v"(lane));
-        const uint32_t e = first + lane;
-        const bool valid = e < last;
-        uint32_t pos = 0;
-        float f0 = -1.0f, f1 = -1.0f, f2 = -1.0f;
-        if (valid) {
-            pos = s_queue[e * QW];
-            const uint4v b = *reinterpret_cast<const uint4v*>(s_queue + e * QW + 4);
-            f0 = __uint_as_float(b.x), f1 = __uint_as_float(b.y), f2 = __uint_as_float(b.z);
-        }
-        const uint32_t g = pos & 7u, x = (pos >> 3) & 7u, y = (pos >> 6) & 7u;
-        const bool n0 = f0 >= 0.0f && !(pos & (1u << 9)), n1 = f1 >= 0.0f && !(pos & (1u << 10)), n2 = f2 >= 0.0f && !(pos & (1u << 11));
-        unsigned long long g0 = __ballot(n0), g1 = __ballot(n1), g2 = __ballot(n2);
-        if (!(g0 | g1 | g2)) return;
-        float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
-        const uint16_t* img16 = reinterpret_cast<const uint16_t*>(s_img);
-        if (__popcll(g0) + __popcll(g1) + __popcll(g2) > 6) {
-            // a cluster: every lane its own samples, component by component
-#pragma unroll 1
-            for (int c = 0; c < 3; ++c) {
-                const bool nd = c == 0 ? n0 : (c == 1 ? n1 : n2);
-                if (__ballot(nd) == 0) continue;
-                int S = 128;
-                if (nd) S = exact_sample_lane(reinterpret_cast<const uint4*>(s_img) + (g * 3 + c) * 8, s_qi[c ? 1 : 0], s_cos, (int)x, (int)y);
-                const float rv = (float)(S - 128);
-                if (c == 0) r0 = rv;
-                else if (c == 1) r1 = rv;
-                else r2 = rv;
-            }
-        } else {
-            const float ccl = cc_of((int)(lane >> 3), (int)(lane & 7));
-            while (g0 | g1 | g2) {   // wave-uniform
-                unsigned long long& mm = g0 ? g0 : (g1 ? g1 : g2);
-                const uint32_t c = g0 ? 0u : (g1 ? 1u : 2u);
-                const uint32_t L = (uint32_t)__builtin_ctzll(mm);
-                mm &= mm - 1;
-                const uint32_t gL = (uint32_t)__builtin_amdgcn_readlane((int)g, (int)L);
-                const int xL = __builtin_amdgcn_readlane((int)x, (int)L), yL = __builtin_amdgcn_readlane((int)y, (int)L);
-                const int F = (int)(int16_t)img16[(gL * 3 + c) * 64 + lane] * (int)s_qi[c ? 1 : 0][lane];   // m_8x8block after MCU.cpp:110-112
-                const int S = exact_sample_wave(ccl * (float)F, s_cos, xL, yL, F != 0);
-                const float rv = (float)(S - 128);
-                if (lane == L) {
-                    if (c == 0) r0 = rv;
-                    else if (c == 1) r1 = rv;
-                    else r2 = rv;
-                }
-            }
-        }
-        if (n0) s_queue[e * QW + 1] = __float_as_uint(r0), s_queue[e * QW + 4] = __float_as_uint(-1.0f);   // key < 0: settled
-        if (n1) s_queue[e * QW + 2] = __float_as_uint(r1), s_queue[e * QW + 5] = __float_as_uint(-1.0f);
-        if (n2) s_queue[e * QW + 3] = __float_as_uint(r2), s_queue[e * QW + 6] = __float_as_uint(-1.0f);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-
     bool have_prev = false;
     size_t prev_off = 0;
     uint32_t prev_nm = 0;
-    uint32_t nq = 0;           // queued positions (wave-uniform)
-    uint32_t nover = 0;        // entries of the overflow list
-    uint32_t nq_total = 0;
     // A tile's inputs: one 16-byte coefficient row of each component block and the three blocks' bounds.  They are asked
-    // for one tile ahead (a second register set: the 16-wavefront workgroup leaves 128 VGPRs per lane), so that a
-    // wavefront's tile costs it its instructions and not a memory round trip on top -- with four wavefronts per SIMD the
-    // others cannot cover that wait.
+    // for one tile ahead (a second register set), so that a wavefront's tile costs it its instructions and not a memory
+    // round trip on top -- with four or five wavefronts per SIMD the others cannot cover that wait.
     // Compact stream: the tile's records (4 bytes per non-zero AC coefficient, ~90 per tile on the 8K workload against 3 KiB of
     // dense rows), its 24 DC values and the bounds are asked for one tile ahead, the two words of the first-record table
     // two tiles ahead (they say where the records are); the blocks are rebuilt in LDS when the tile's turn comes.
@@ -1048,13 +1072,13 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         uint32_t rs, rn;         // ... first record and record count (wave-uniform)
     };
     auto tile_records = [&](uint32_t tk, uint32_t& rs, uint32_t& rn) {
-        const uint32_t tile = wg_tile0 + tk;
+        const uint32_t tile = tile_of(tk);
         const uint32_t a = p.tile_start[tile], b = p.tile_start[tile + 1];   // wave-uniform addresses: scalar loads
         rs = a;
         rn = (b >= a && b <= p.rec_cap && b - a <= 24u * 63u) ? b - a : 0u;   // (a corrupt stream may leave anything in the table)
     };
     auto issue_loads = [&](uint32_t tk, TileIn& in, uint32_t rs, uint32_t rn) {
-        const uint32_t tile = wg_tile0 + tk;
+        const uint32_t tile = tile_of(tk);
         const uint32_t trow = tile_row(p, tile), tcol = tile - trow * p.tiles_w;
         const uint32_t m0 = tcol * TILE_MCUS;
         const uint32_t nm = min((uint32_t)TILE_MCUS, p.mcus_w - m0);
@@ -1078,16 +1102,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             in.dcw = l < 24u ? (uint32_t)(uint16_t)p.dc16[mcu_ld * 3 + l] : 0u;
         } else {
             const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(p.coef + mcu_ld * 192) + (lane_mcu * 384u + (uint32_t)u * 16u));
-#if defined(KPEG_ABLATE_HALFLINE)
-            // timing experiment: rows 4..7 (the second 64 bytes of every block) are not loaded -- does half a line cost half?
-            in.d0 = in.d1 = in.d2 = make_uint4(0, 0, 0, 0);
-            if (u < 4) in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
-#elif defined(KPEG_ABLATE_QUARTERLINE)
-            in.d0 = in.d1 = in.d2 = make_uint4(0, 0, 0, 0);
-            if (u < 2) in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
-#else
             in.d0 = src[0], in.d1 = src[8], in.d2 = src[16];
-#endif
         }
         const float* eb = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(p.ebound + mcu_ld * 3) + lane_mcu * 12u);
         in.e0 = eb[0], in.e1 = eb[1], in.e2 = eb[2];
@@ -1107,11 +1122,9 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
         if (tilek_next < wg_ntiles) tile_records(tilek_next, rs_next, rn_next);
     for (;;) {
         const uint32_t tilek = tilek_cur;              // this tile's number inside the workgroup's range
-        const bool more = tilek < wg_ntiles;           // wave-uniform
-        const uint32_t tile = wg_tile0 + tilek;
-        uint32_t tilek_after = 0;
-        if (more) {
-        tilek_after = take_tile();
+        if (!(tilek < wg_ntiles)) break;               // wave-uniform
+        const uint32_t tile = tile_of(tilek);
+        const uint32_t tilek_after = take_tile();
         if constexpr (COMPACT)
             if (tilek_after < wg_ntiles) tile_records(tilek_after, rs_after, rn_after);   // two tiles ahead: nothing waits for these
         if constexpr (!PREFETCH) issue_loads(tilek, cur, 0, 0);
@@ -1151,22 +1164,23 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             if (tilek_next < wg_ntiles) issue_loads(tilek_next, nxt, rs_next, rn_next);
             asm volatile("" ::: "memory");
         }
-        // The first word of rows 0 and 1 of the MCU's three blocks (coefficients (0,0),(0,1) and (1,0),(1,1)): they sit on
-        // lanes 0 and 4 of the group.  A queued pixel takes them along, so the fix-up pass settles corner-only blocks (nine
-        // unsafe samples in ten) without touching memory.
-        constexpr bool STASH = COMPACT || KPEG_K4_STASH_DENSE;
-        const int lrow0 = tid & 56, lrow1 = lrow0 | 4;
-        uint32_t cw00 = 0, cw01 = 0, cw10 = 0, cw11 = 0, cw20 = 0, cw21 = 0;
-        if constexpr (STASH && !COMPACT) {   // (the compact path reads them from the tile's LDS image when it queues a pixel)
-            cw00 = (uint32_t)__shfl((int)d0.x, lrow0), cw01 = (uint32_t)__shfl((int)d0.x, lrow1);
-            cw10 = (uint32_t)__shfl((int)d1.x, lrow0), cw11 = (uint32_t)__shfl((int)d1.x, lrow1);
-            cw20 = (uint32_t)__shfl((int)d2.x, lrow0), cw21 = (uint32_t)__shfl((int)d2.x, lrow1);
-        }
         const size_t cur_off = tile_offset(trow, m0);
         if (have_prev) write_back(prev_off, prev_nm);  // LDS still holds the previous tile
         have_prev = true;
         prev_off = cur_off;
         prev_nm = nm;
+
+        // Quantised high frequencies are mostly zero: if no block of this wavefront has a coefficient outside
+        // its top-left 6x6 (luma) / 4x4 (chroma) corner, the terms of the empty rows and columns are left out
+        // (same floats as the full transform, see row_idct8).  8K q75: luma 6x6 for 98 % of the tiles, chroma 4x4 for 99 %.
+        // All four wave-uniform conditions of a tile are taken together, ahead of the first branch on any of them: a scalar
+        // branch on a vector compare stalls the wavefront until the compare has left the vector pipe, once instead of four times.
+        const bool big0 = __ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0) != 0;
+        const bool big1 = __ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0) != 0;
+        const bool big2 = __ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0) != 0;
+        // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
+        const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
+        const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
 
         float v[3][8];
 #ifdef KPEG_ABLATE_IDCT
@@ -1175,55 +1189,27 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             v[1][i] = __uint_as_float(d1.y + i) * 1e-30f;
             v[2][i] = __uint_as_float(d2.z + i) * 1e-30f;
         }
+        (void)big0, (void)big1, (void)big2;
 #else
-        // Quantised high frequencies are mostly zero: if no block of this wavefront has a coefficient outside
-        // its top-left 6x6 (luma) / 4x4 (chroma) corner, the terms of the empty rows and columns are left out
-        // (same floats as the full transform, see row_idct8).  8K q75: luma 6x6 for 98 % of the tiles, chroma 4x4 for 99 %.
-#if KPEG_K4_LUMA4
-        // (a third luma size: 4x4 -- what smooth content quantises to)
-        if (__ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0)) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
-        else if (__ballot((d0.z | (u >= 4 ? (d0.x | d0.y) : 0u)) != 0)) block_fast<6>(d0, lc, &s_m[0][u * 8], 0, v[0]);
-        else block_fast<4>(d0, lc, &s_m[0][u * 8], 0, v[0]);
-#else
-        if (__ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0)) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
+        if (big0) block_fast<8>(d0, lc, &s_m[0][u * 8], 0, v[0]);
         else block_fast<6>(d0, lc, &s_m[0][u * 8], 0, v[0]);
-#endif
-#if KPEG_K4_CHROMA2
-        // chroma blocks of smooth content rarely have anything outside their 2x2 corner (DC and the two first-order terms)
-        if (__ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0)) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
-        else if (__ballot((d1.y | (u >= 2 ? d1.x : 0u)) != 0)) block_fast<4>(d1, lc, &s_m[1][u * 8], 1, v[1]);
-        else block_fast<2>(d1, lc, &s_m[1][u * 8], 1, v[1]);
-        if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
-        else if (__ballot((d2.y | (u >= 2 ? d2.x : 0u)) != 0)) block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
-        else block_fast<2>(d2, lc, &s_m[1][u * 8], 1, v[2]);
-#else
-        if (__ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0)) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
+        if (big1) block_fast<8>(d1, lc, &s_m[1][u * 8], 1, v[1]);
         else block_fast<4>(d1, lc, &s_m[1][u * 8], 1, v[1]);
-        if (__ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0)) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
+        if (big2) block_fast<8>(d2, lc, &s_m[1][u * 8], 1, v[2]);
         else block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
-#endif
 #endif
         // |fast - rint(fast)| + nthr >= 0  <=>  within the block's bound of a rounding boundary
         const float nthr0 = fabsf(e0) - 0.5f, nthr1 = fabsf(e1) - 0.5f, nthr2 = fabsf(e2) - 0.5f;
-        // chroma samples of this MCU may exceed the f32 colour arithmetic's proven range (see block_ebound)
-        const bool wide = (((__float_as_uint(e1) | __float_as_uint(e2)) & 1u) != 0) && active;
-        const bool any_wide = __ballot(wide) != 0;   // wave-uniform, rare
 
-        // Level shift + colour for the 8 pixels of this lane's row.  Per pixel one float key says
-        // whether the reference-order evaluation is needed (key >= 0): a fast value within its block's
-        // bound of a rounding boundary, or a G term too close to an integer for the f32 arithmetic.
-        // Nearly every wavefront has a few such pixels (true ties are structural: equal and opposite
-        // (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5 exactly): their positions are
-        // queued straight from this loop with ballot compaction (no atomics, no second pass).
+        // Level shift + colour for the 8 pixels of this lane's row.  Per pixel the sign of one word says whether the
+        // reference-order evaluation is needed (sign clear): a fast value within its block's bound of a rounding boundary,
+        // or a G term too close to an integer for the f32 arithmetic.  Nearly every wavefront has a few such pixels (true
+        // ties are structural: equal and opposite (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5
+        // exactly); their signs are shifted into `ub`, one bit per pixel column.
         uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
-        const uint32_t nq_tile = nq;
-        const uint32_t pos_lane = (uint32_t)grp | ((uint32_t)lane8 << 3) | (tilek << 12) | ((__float_as_uint(e0) >> 31) << 9) |
-                                  ((__float_as_uint(e1) >> 31) << 10) | ((__float_as_uint(e2) >> 31) << 11);
-        const unsigned long long active_mask = __ballot(active);
-        bool pushed_nc = false;   // compact stream: this tile queued a pixel with an unsafe sample in a block that is not corner-only
-        uint32_t nc_lane = 0;
-        constexpr int PG = COMPACT ? KPEG_PUSH_GROUP_COMPACT : KPEG_PUSH_GROUP;   // pixel columns per unsafe-pixel test
-        uint32_t gsafe = 0x80000000u, sf[PG];
+        uint32_t ubY = 0, ubB = 0, ubR = 0, ubG = 0;   // per component and for the G term: bit 7 - i = pixel column i is safe
+        uint32_t hp[3][4];                              // the rounded samples as f16 pairs
+        float py = 0.0f, pb = 0.0f, pr = 0.0f;          // the even column's, until its odd neighbour's are there
         // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
         auto pixel_loop = [&](auto with_wide) {
 #pragma unroll
@@ -1263,74 +1249,31 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
                         kg = 0x80000000u;   // G is exact here
                     }
                 }
-                const uint32_t safe = __float_as_uint(fy) & __float_as_uint(fb) & __float_as_uint(fr) & kg;
                 pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
                 pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
                 pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
-#if defined(KPEG_ABLATE_PUSH_KEEPSAFE)
-                // timing experiment: the safety arithmetic stays (kept alive), no test, no queue
-                asm volatile("" ::"v"(safe));
-#elif !defined(KPEG_ABLATE_PUSH)
-                // A scalar branch on a vector compare costs a wavefront ~175 cycles (the VALU result has to reach the scalar
-                // unit): one test per pixel column -- eight per tile, plus one more in every taken branch -- was 13 us of the
-                // kernel (profiles/r02: ablations).  So: one test per GROUP of KPEG_PUSH_GROUP columns; a group with an unsafe
-                // pixel (2.5 pixels per tile on the 8K workload) takes its ballots together and queues its pixels with
-                // ballot compaction (no atomics).
-                sf[i % PG] = safe;
-                gsafe &= safe;
-                if ((i % PG) == PG - 1) {
-                    if (__ballot((int)gsafe >= 0) & active_mask) {
-                        unsigned long long gb[PG];
-#pragma unroll
-                        for (int j = 0; j < PG; ++j) gb[j] = __ballot((int)sf[j] >= 0) & active_mask;
-                        uint32_t base_slot = nq;
-#pragma unroll
-                        for (int j = 0; j < PG; ++j) {
-                            const int ii = i - (PG - 1) + j;
-                            const unsigned long long bal = gb[j];
-                            const uint32_t slot = base_slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0));
-#ifdef KPEG_ABLATE_PUSHBODY
-                            if (slot == 0xFFFFFFFFu)   // timing experiment: the tests and the count stay, the entry is never written
-#endif
-                            if ((int)sf[j] >= 0 && active) {
-                                // the pixel's rounded samples and keys again, from the fast values (cheaper than keeping them)
-                                const float wy = v[0][ii], wb = v[1][ii], wr = v[2][ii];
-                                const float qy = __builtin_rintf(wy), qb = __builtin_rintf(wb), qr = __builtin_rintf(wr);
-                                const float gy = fabsf(wy - qy) + nthr0, gbk = fabsf(wb - qb) + nthr1, gr = fabsf(wr - qr) + nthr2;
-                                const uint32_t pw = pos_lane | ((uint32_t)ii << 6);
-                                if (slot < QUEUE_CAP) {
-                                    uint32_t* q = s_queue + slot * QW;
-                                    q[0] = pw;
-                                    q[1] = __float_as_uint(qy), q[2] = __float_as_uint(qb), q[3] = __float_as_uint(qr);
-                                    q[4] = __float_as_uint(gy), q[5] = __float_as_uint(gbk), q[6] = __float_as_uint(gr);
-                                    // the 2x2 corner of the pixel's three blocks (rows 0 and 1, columns 0 and 1)
-                                    if constexpr (COMPACT) {
-                                        const uint32_t* im = s_img + (grp * 3) * 32;   // block c at + 32 c words: rows 0 and 1 at words 0 and 4
-                                        q[8] = im[0], q[9] = im[4], q[10] = im[32], q[11] = im[36], q[12] = im[64], q[13] = im[68];
-                                    } else if constexpr (STASH) {
-                                        q[8] = cw00, q[9] = cw01, q[10] = cw10, q[11] = cw11, q[12] = cw20, q[13] = cw21;
-                                    }
-                                } else {
-                                    s_over[slot - QUEUE_CAP] = (uint16_t)(pw & 0xFFFu);
-                                }
-                                if constexpr (COMPACT)
-                                    nc_lane |= (~__float_as_uint(gy) & ~__float_as_uint(e0)) | (~__float_as_uint(gbk) & ~__float_as_uint(e1)) |
-                                               (~__float_as_uint(gr) & ~__float_as_uint(e2));   // sign set: unsafe (key >= 0) in a block whose bound is positive (not corner-only)
-                            }
-                            base_slot += __popcll(bal);
-                        }
-                        nq = base_slot;
-                    }
-                    gsafe = 0x80000000u;
-                }
+#if defined(KPEG_ABLATE_PUSH)
+                (void)fy, (void)fb, (void)fr, (void)kg;   // timing experiment: no unsafe-pixel arithmetic survives
 #else
-                (void)safe;
+                // the signs into the four bytes: u << 1 | sign (one v_alignbit each, in place of the ANDs that used to merge them)
+                ubY = __builtin_amdgcn_alignbit(ubY, __float_as_uint(fy), 31);
+                ubB = __builtin_amdgcn_alignbit(ubB, __float_as_uint(fb), 31);
+                ubR = __builtin_amdgcn_alignbit(ubR, __float_as_uint(fr), 31);
+                ubG = __builtin_amdgcn_alignbit(ubG, kg, 31);
+                if (i & 1) {
+                    // two columns' rounded samples as an f16 pair (exact: integers, |.| <= 2048 wherever the bound is finite enough to matter;
+                    // fx_flush treats a larger one as unsafe)
+                    hp[0][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(py, ry));
+                    hp[1][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pb, rb));
+                    hp[2][i >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pr, rr));
+                } else {
+                    py = ry, pb = rb, pr = rr;
+                }
 #endif
             }
         };
         if (any_wide) pixel_loop(std::true_type{});
         else pixel_loop(std::false_type{});
-        if constexpr (COMPACT) pushed_nc = __ballot((int)nc_lane < 0) != 0;
         {
             // 24 bytes of pixel row lane8, MCU grp (groups beyond nm write garbage that is never stored)
             uint2* dst = reinterpret_cast<uint2*>(s_tile + lane8 * TILE_ROW_STRIDE + grp * 24);
@@ -1338,65 +1281,113 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
             dst[1] = make_uint2(pk[2], pk[3]);
             dst[2] = make_uint2(pk[4], pk[5]);
         }
-        nq_total += nq - nq_tile;
-        if (nq > QUEUE_CAP) {   // the rest went to the overflow list
-            nover = nq - QUEUE_CAP;
-            nq = QUEUE_CAP;
-        }
-        if constexpr (COMPACT) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#ifndef KPEG_ABLATE_RESOLVE
-            if (pushed_nc) resolve_noncorner(min(nq_tile, (uint32_t)QUEUE_CAP), nq);   // while this tile's image stands
+#if !defined(KPEG_ABLATE_PUSH)
+        {
+            // One compare, one ballot: the tile loop's only test on what the pixel loop found.  The rows that have a marked pixel join the
+            // queue, at ranks counted from the same ballot; the count is a scalar.
+            const uint32_t marked = active ? ~(ubY & ubB & ubR & ubG) & 0xFFu : 0u;   // bit 7 - i = pixel column i needs the reference-order evaluation
+            const unsigned long long mbal = __ballot(marked != 0);
+            if (mbal) {   // wave-uniform: two tiles in five on the 8K workload
+#if !defined(KPEG_COUNT_NC) && !defined(KPEG_COUNT_NCTILES) && !defined(KPEG_COUNT_ROWS)
+                fx_lane += (uint32_t)__popc(marked);
+#elif defined(KPEG_COUNT_ROWS)
+                fx_lane += marked ? 1u : 0u;
 #endif
+                if (!p.skip_exact) {
+                    const uint32_t nrow = (uint32_t)__popcll(mbal);
+                    if (qcount + nrow > (uint32_t)ROWQ_CAP) flush_rows();   // (the rows queued so far are of tiles already written back)
+                    const uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mbal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mbal, 0));
+                    uint32_t* const entry = s_rowq + (marked ? slot : 0u) * ROWQ_WORDS;
+                    uint32_t nc = 0, inf = 0;
+                    if (marked) {
+                        uint4v* row = reinterpret_cast<uint4v*>(entry);
+                        const uint4v h0 = {hp[0][0], hp[0][1], hp[0][2], hp[0][3]}, h1 = {hp[1][0], hp[1][1], hp[1][2], hp[1][3]}, h2 = {hp[2][0], hp[2][1], hp[2][2], hp[2][3]};
+                        uint4v h3 = {(ubY & 0xFFu) | ((ubB & 0xFFu) << 8) | ((ubR & 0xFFu) << 16) | (ubG << 24), (tile << 6) | (uint32_t)tid, 0u, 0u};
+                        uint4v h4 = {0u, 0u, 0u, 0u};
+                        if constexpr (COMPACT) {
+                            uint32_t gl = (uint32_t)tid;
+                            asm volatile("" : "+v"(gl));   // (worked out here, not kept in a register across the loop)
+                            const uint32_t* b32 = s_img + (gl >> 3) * 3 * 32;   // the MCU's three blocks, 32 words each
+                            h3.z = b32[0], h3.w = b32[4], h4.x = b32[32], h4.y = b32[36], h4.z = b32[64], h4.w = b32[68];
+                            // samples of blocks that are not corner-only (the bound's sign is clear) are settled while the blocks stand
+                            nc = (__float_as_int(e0) < 0 ? 0u : ~ubY & 0xFFu) | (__float_as_int(e1) < 0 ? 0u : (~ubB & 0xFFu) << 8) | (__float_as_int(e2) < 0 ? 0u : (~ubR & 0xFFu) << 16);
+                            inf = (e0 == __builtin_inff() ? 1u : 0u) | (e1 == __builtin_inff() ? 2u : 0u) | (e2 == __builtin_inff() ? 4u : 0u);
+                        }
+                        row[0] = h0, row[1] = h1, row[2] = h2, row[3] = h3, row[4] = h4;
+                    }
+                    qcount += nrow;
+                    if constexpr (COMPACT) {
+#if defined(KPEG_COUNT_NC)
+                        fx_lane += (uint32_t)__popc(nc);
+#elif defined(KPEG_COUNT_NCTILES)
+                        fx_lane += (tid == 0 && __ballot(nc != 0)) ? 1u : 0u;
+#endif
+                        if (__ballot(nc != 0)) {   // wave-uniform: one marked tile in ten
+                            KPEG_STAMP_BEGIN
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const uint32_t total = (uint32_t)__popcll(__ballot((nc & 0xFFu) != 0)) + (uint32_t)__popcll(__ballot((nc & 0xFF00u) != 0)) +
+                                                   (uint32_t)__popcll(__ballot((nc & 0xFF0000u) != 0));   // rows-and-components
+#ifndef KPEG_FX_FEW_MAX
+#define KPEG_FX_FEW_MAX 3u
+#endif
+                            if (total > KPEG_FX_FEW_MAX || __ballot(inf != 0))
+#ifdef KPEG_FX_SKIP_MANY
+                                ;
+                            else if (false)
+#endif
+                                fx_noncorner_many((lds_u32*)entry, (lds_cu32*)s_img, (lds_cu32*)s_qi, (lds_cf64*)s_cos, nc, inf,
+                                                  (__attribute__((address_space(3))) uint8_t*)(s_tile + lane8 * TILE_ROW_STRIDE + grp * 24));
+                            else
+#ifdef KPEG_FX_SKIP_FEW
+                                if (false)
+#endif
+                                fx_noncorner_few((lds_u32*)entry, (lds_cu32*)s_img, (lds_cu32*)s_qi, (lds_cf64*)s_cos, nc);
+                            KPEG_STAMP_END(stamp_nc, stamp_nnc)
+                        }
+                    }
+                }
+            }
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the next iteration writes this tile back before its own colour phase overwrites the LDS tile
-        }
-        // Fix-ups are due: a pass's worth of queued pixels or the end of this wavefront's tiles.  Few
-        // values of the tile loop are live here.  Every tile a queued position refers to must have been stored before
-        // (run_fixups waits for the stores to be performed before it patches bytes of theirs).
-        if (nq >= QUEUE_FLUSH || (!more && nq)) {   // wave-uniform
-            if (have_prev) write_back(prev_off, prev_nm);
-            have_prev = false;
-            if (!p.skip_exact) run_fixups(nq, nover, tilek);
-            nq = 0;
-            nover = 0;
-        }
-        if (!more) break;
         if constexpr (PREFETCH) cur = nxt;
         tilek_cur = tilek_next;
         tilek_next = tilek_after;
         rs_next = rs_after, rn_next = rn_after;
     }
     if (have_prev) write_back(prev_off, prev_nm);
-#if defined(KPEG_COUNT_COOP) || defined(KPEG_COUNT_MANY) || defined(KPEG_COUNT_FLUSH) || defined(KPEG_COUNT_CORNER)
-    nq_total = dbg_count;
-#else
-    (void)dbg_count;
+#ifdef KPEG_K4_STAMP
+    const unsigned long long stamp_r1 = __builtin_amdgcn_s_memrealtime();   // the tile loop is done
 #endif
+    if (qcount) flush_rows();   // what is left (the last tile has just been handed to the memory system)
 #ifdef KPEG_K4_STAMP
     if (tid == 0) {
         const unsigned long long dc = __builtin_amdgcn_s_memtime() - stamp_c0, dr = __builtin_amdgcn_s_memrealtime() - stamp_r0;
         const uint32_t w = blockIdx.x * K4_WAVES + wave;
         if (w < 8192) {
             // every wavefront's start, end (100 MHz ticks), lifetime in shader cycles, to a slot of its own (a buffer nothing else reads)
+            g_k4_stamp[32768 + w * 4 + 0] = stamp_r1;
+            g_k4_stamp[32768 + w * 4 + 1] = stamp_flush | (stamp_nflush << 48);
+            g_k4_stamp[32768 + w * 4 + 2] = stamp_nc | (stamp_nnc << 48);
+            g_k4_stamp[32768 + w * 4 + 3] = fx_lane;
             g_k4_stamp[w * 4 + 0] = stamp_r0;
             g_k4_stamp[w * 4 + 1] = stamp_r0 + dr;
             g_k4_stamp[w * 4 + 2] = dc;
-            // unsafe pixels [63:48] | XCC_ID [35:32] | HW_ID [31:0] (wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
-            g_k4_stamp[w * 4 + 3] = ((unsigned long long)(nq_total & 0xFFFFu) << 48) |
-                                    ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 32) |
+            // XCC_ID [35:32] | HW_ID [31:0] (wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+            g_k4_stamp[w * 4 + 3] = ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 15u) << 32) |
                                     __builtin_amdgcn_s_getreg(4 | (31 << 11));
         }
     }
 #endif
-    // The workgroup's last wavefront adds the workgroup's count of unsafe pixels to the statistics (spread over 256 words:
+    // The workgroup's last wavefront adds the workgroup's count of settled pixels to the statistics (spread over 256 words:
     // a single hot word serialises in L2) and takes the workgroup's end-of-call ticket.
+    const uint32_t fx_settled = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(fx_lane), 63);
     uint32_t last_of_wg = 0;
     if (tid == 0) {
-        if (nq_total) atomicAdd(&s_wg[1], nq_total);
+        if (fx_settled) atomicAdd(&s_wg[1], fx_settled);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         last_of_wg = atomicAdd(&s_wg[0], 1u) == (uint32_t)K4_WAVES - 1 ? 1u : 0u;
     }
@@ -1409,5 +1400,6 @@ __global__ __launch_bounds__(K4_THREADS) void k_idct_colour_fast(IdctParams p, Q
     }
     status_epilogue(p.status, p.h_status, gridDim.x, p.keep_status, dep);
 }
+
 
 }  // namespace kpeg_dev

@@ -255,7 +255,7 @@
                     // even mantissa, rounded up; lowest bit = chroma samples may leave the f32 colour range (Asum >= 249)
                     const uint32_t Eb = ((__float_as_uint(E) + 1u) & ~1u) | ((cur_chroma && !(Asum < 249.0f)) ? 1u : 0u);
                     const float Ef = __uint_as_float(Eb);
-                    a.ebound[gb] = !(Asum < 4000.0f) ? __builtin_inff() : ((int)ncw < 0 ? Ef : -Ef);
+                    a.ebound[gb] = !(Asum < 2040.0f) ? __builtin_inff() : ((int)ncw < 0 ? Ef : -Ef);
                 }
                 Asum = 0.0f;
                 nnz = 0;
@@ -305,7 +305,7 @@
         const float E = n ? (0x1.004p-24f * A) * ((float)n + 14.5f) : 0.0f;
         const float Ef = __uint_as_float(((__float_as_uint(E) + 1u) & ~1u) | ((chroma && !(A < 249.0f)) ? 1u : 0u));
         // always stored: k_sync_write makes no presets, so a bound left alone would be whatever an earlier call wrote there
-        a.ebound[blk] = A < 4000.0f ? (crn ? -Ef : Ef) : __builtin_inff();
+        a.ebound[blk] = A < 2040.0f ? (crn ? -Ef : Ef) : __builtin_inff();
     };
     const uint32_t nown = min((uint32_t)OWN, nsub - i0);
     const bool tail = threadIdx.x == nown - 1 && (share.z & SH_OPEN);   // the workgroup's last lane leaves a block open

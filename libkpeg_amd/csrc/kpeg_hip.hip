@@ -1248,7 +1248,7 @@ extern "C" int kpeg_hip_debug_entropy_stamps(int which, unsigned long long* out,
 // diagnostic build only (tools/k4_clock.py): per-wavefront start/end stamps of the last K4 launch
 extern "C" int kpeg_hip_debug_k4_stamps(unsigned long long* out, int n)
 {
-    if (n > 8192 * 4) n = 8192 * 4;
+    if (n > 8192 * 8) n = 8192 * 8;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(kpeg_dev::g_k4_stamp), (size_t)n * 8) == hipSuccess ? 0 : -2;
 }
 #endif

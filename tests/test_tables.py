@@ -49,7 +49,7 @@ def test_kernel_error_constant_covers_the_derived_bound():
     # K2 writes the same bound formula as block_ebound()
     ent = open(os.path.join(CSRC, "entropy.hip.h")).read() + open(os.path.join(CSRC, "k2_core.inc.h")).read()
     assert "(0x1.004p-24f * Asum) * ((float)nnz + %sf)" % ("%.1f" % kk) in ent
-    assert "Asum < 249.0f" in ent and "Asum < 4000.0f" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM 4000.0f" in src
+    assert "Asum < 249.0f" in ent and "Asum < 2040.0f" in ent and "KPEG_A_LIM_CHROMA 249.0f" in src and "KPEG_A_LIM 2040.0f" in src
     assert "(__float_as_uint(E) + 1u) & ~1u" in ent and "(__float_as_uint(E) + 1u) & ~1u" in src   # same flag encoding on both sides
     assert "#define KPEG_U 0x1.004p-24f" in src
 
@@ -95,7 +95,7 @@ def test_fast_path_error_bound_holds_empirically():
 def test_colour_arithmetic_is_exact_over_its_whole_range():
     """K4 hands v_cvt_pk_u8_f32 (round to nearest even, saturating) the values fma(Cr', 1.402f, Yo), fma(Cb', 1.772f, Yo)
     and Yo - ceil(t) with Yo = rounded luma + 127.501f.  Every case the fast path admits (|chroma| <= 249 by
-    KPEG_A_LIM_CHROMA, |luma| <= 4000 by KPEG_A_LIM) must give the reference's clamp(floor(exact value)) (MCU.cpp:259-265
+    KPEG_A_LIM_CHROMA, |luma| <= 2041 by KPEG_A_LIM; the test covers twice that) must give the reference's clamp(floor(exact value)) (MCU.cpp:259-265
     evaluates in double: exact unless the value is an integer, which happens only for chroma 0)."""
     f32 = np.float32
     ry = np.arange(-4100, 4101, dtype=np.float64)

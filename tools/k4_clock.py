@@ -26,6 +26,8 @@ def main():
     d_rgb = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
     ctx = K.Context(0, lib=lib)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("KPEG_IDCT_MODE"):
+        ctx.set_idct_mode(int(os.environ["KPEG_IDCT_MODE"]))   # 2: marked pixels are counted, not settled (wrong pixels; what the tile loop alone does)
     for _ in range(200):   # a few ms of back-to-back launches before the measured one
         ctx.decode_scan_dev(frame, d_scan.data_ptr(), d_scan.numel(), d_rgb.data_ptr())
     ctx.sync()
@@ -33,9 +35,11 @@ def main():
     for rep in range(3):
         ctx.decode_scan_dev(frame, d_scan.data_ptr(), d_scan.numel(), d_rgb.data_ptr())
         ctx.sync()
-        st = np.zeros(8192 * 4, np.uint64)
+        st = np.zeros(8192 * 8, np.uint64)
         assert lib.kpeg_hip_debug_k4_stamps(st.ctypes.data_as(ctypes.c_void_p), st.size) == 0
-        st = st.reshape(-1, 4).astype(np.int64)
+        ex = st[8192 * 4:].reshape(-1, 4).astype(np.int64)   # tile loop done, cycles in fx_flush | calls << 48, cycles in the non-corner block | times << 48
+        st = st[:8192 * 4].reshape(-1, 4).astype(np.int64)
+        ex = ex[st[:, 1] > 0]
         st = st[st[:, 1] > 0]
         nwaves = len(st)
         t0 = st[:, 0].min()
@@ -43,6 +47,14 @@ def main():
         unsafe = (st[:, 3] >> 48) & 0xFFFF
         print("K4: %d wavefronts, mean lifetime %.1f us, shader clock %.0f MHz" % (nwaves, life.mean(), st[:, 2].sum() / (st[:, 1] - st[:, 0]).sum() * 100.0))
         print("   us, percentiles 0 10 50 90 99 100: start %s | end %s | lifetime %s" % (pct(start), pct(end), pct(life)))
+        if ex[:, 0].max() > 0:
+            clk = st[:, 2].sum() / (st[:, 1] - st[:, 0]).sum() * 100.0   # MHz
+            m48 = (1 << 48) - 1
+            tail = (st[:, 1] - ex[:, 0]) / 100.0
+            fl_us, fl_n = (ex[:, 1] & m48) / clk, ex[:, 1] >> 48
+            nc_us, nc_n = (ex[:, 2] & m48) / clk, ex[:, 2] >> 48
+            print("   tile loop done at %s | from there to the end %s" % (pct((ex[:, 0] - t0) / 100.0), pct(tail)))
+            print("   fx_flush: calls per wave %s, us per wave %s | non-corner block: times %s, us %s" % (pct(fl_n), pct(fl_us), pct(nc_n), pct(nc_us)))
         if rep:
             continue
         xcc, hw = (st[:, 3] >> 32) & 15, st[:, 3] & 0xFFFFFFFF
