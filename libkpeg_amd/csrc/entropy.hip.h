@@ -279,6 +279,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t k0_slot[64], k0_top;   // K0's two-level ticket (restart segments: the last workgroup to finish sets the segments up)
     uint32_t k1_order;   // K1's chained pass: logical workgroup index = the order in which workgroups start (K0 clears it)
     uint32_t fused_fail; // == the call's number: k_sync_write could not finish the call (the three launches behind it do)
+    uint32_t repaired;   // workgroups of k_sync_write that found their entry state wrong and put it right themselves (ever: tools read the difference)
 };
 
 // Waits between workgroups never rest on the order in which the hardware dispatches blockIdx (HIP promises none):
@@ -292,6 +293,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
 //    KPEG_HIP_E_DEVICE instead of the queue hanging.
 constexpr unsigned long long K0_SPIN_TICKS = 50000ull;        // 0.5 ms (a predecessor's 8 KiB take microseconds), then the fallback
 constexpr unsigned long long K1_SPIN_TICKS = 2000000000ull;   // 20 s: a predecessor's wait includes the whole chain before it
+constexpr uint32_t FUSED_MAX_WG = 4096;   // k_sync_write: every workgroup reads every record before its own -- 8 M records at this size, a few per cent of such a call's time
 constexpr unsigned long long FUSED_SPIN_TICKS = 30000ull;     // 0.3 ms (three times what the kernel takes on an 8K image): k_sync_write's waits; then the launches behind it take over
 struct SpinGuard {
     unsigned long long t0 = 0, limit;
@@ -1264,10 +1266,11 @@ struct SyncArgs {
     // k_sync_write (K1's pass 0 and K2 in one kernel): the call's number (never 0; 0 = not that path), and two words per
     // workgroup that take it: its presets are done / its totals and states are published
     uint32_t gen;
-    unsigned long long* pub;   // [nwg_cap][PUB_WORDS]: value | call number << 32, relaxed atomics both ways
+    unsigned long long* pub;   // [nwg_cap][PUB_WORDS] then [nwg_cap][PUB2_WORDS]: value | call number << 32, relaxed atomics both ways
 };
 constexpr uint64_t X_NONE = ~0ull;
 constexpr uint32_t PUB_WORDS = 9;   // blocks, dc0, dc1, dc2, records, exit state lo / hi, assumed entry state lo / hi
+constexpr uint32_t PUB2_WORDS = 5;  // a workgroup that repaired itself: blocks, dc0, dc1, dc2, records once more, at pub + nwg_cap PUB_WORDS
 
 // Appends v to list[] for every lane that wants to; call with the whole wavefront converged.
 __device__ __forceinline__ void push_item(bool want, uint32_t v, uint16_t* list, uint32_t* counter)
@@ -1685,103 +1688,200 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         // (the body's thread 0 has published the totals, the last exit state and the assumption: a.gen != 0)
     }
     const uint32_t gi = blockIdx.x, ti = threadIdx.x;
-    __builtin_amdgcn_s_setprio(0);
+    const uint64_t k1_last = s_edge[1];   // this workgroup's last exit state, as published (written before the body's last barrier)
+    // The exit state this workgroup's first own item has to have started from: the last one of the workgroup before.  Asked for now,
+    // looked at behind the hand-over below (thread 0).
+    unsigned long long xq0 = 0, xq1 = 0;
+    if (ti == 0 && gi > 0) {
+        xq0 = __hip_atomic_load(ka.pub + (size_t)(gi - 1) * PUB_WORDS + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xq1 = __hip_atomic_load(ka.pub + (size_t)(gi - 1) * PUB_WORDS + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #if KPEG_SYNC_STATS
     const uint64_t tw0 = __builtin_amdgcn_s_memtime();   // K1's part is over for the whole workgroup, its totals are published
 #endif
     // ---- what K1's lanes know, handed to K2's lanes: item j of the workgroup sits on lane j + wu there, on lane j here; then K2's
-    // scan inside the workgroup.  None of it needs another workgroup: it is done before the wait below, not behind it. ----
+    // scan inside the workgroup.  None of it needs another workgroup: it is done before the waits below, not behind them. ----
     int4* const s_pre = reinterpret_cast<int4*>(s_lutx);
     uint32_t* const s_prer = s_lutx + SYNC_WG * 4;
     int4* const s_wred = s_red;
     uint32_t* const s_wredr = s_redn;
     uint64_t* const s_x = reinterpret_cast<uint64_t*>(s_lutx);
-    __syncthreads();   // (K1's last readers of s_red / s_redn and of s_lutx are done)
-    if (k1_own) s_x[ti - k1_wu] = k1_exit;
-    __syncthreads();
     const uint32_t i = i0 + ti;
     const bool valid = ti < OWN && i < nsub;
-    uint64_t x_prev = valid && ti > 0 ? s_x[ti - 1] : 0ull;   // (lane 0's is the predecessor workgroup's last exit state: below)
-    __syncthreads();
-    if (k1_own) {
-        s_pre[ti - k1_wu] = k1_cnt;
-        s_prer[ti - k1_wu] = k1_nrec;
-    }
-    __syncthreads();
-    const int4 cnt_i = valid ? s_pre[ti] : make_int4(0, 0, 0, 0);
-    const uint32_t nrec_i = valid ? s_prer[ti] : 0u;
-    __syncthreads();
+    uint64_t x_prev = 0;
+    int4 cnt_i = make_int4(0, 0, 0, 0);
+    uint32_t nrec_i = 0;
+    auto hand_over = [&]() {
+        __syncthreads();   // (K1's last readers of s_red / s_redn and of s_lutx are done)
+        if (k1_own) s_x[ti - k1_wu] = k1_exit;
+        __syncthreads();
+        x_prev = valid && ti > 0 ? s_x[ti - 1] : 0ull;   // (lane 0's is the predecessor workgroup's last exit state: below)
+        __syncthreads();
+        if (k1_own) {
+            s_pre[ti - k1_wu] = k1_cnt;
+            s_prer[ti - k1_wu] = k1_nrec;
+        }
+        __syncthreads();
+        cnt_i = valid ? s_pre[ti] : make_int4(0, 0, 0, 0);
+        nrec_i = valid ? s_prer[ti] : 0u;
+        __syncthreads();
 #include "k2_scan.inc.h"
-    // ---- every workgroup before this one: wait for what it published, add it up, check its assumption ----
-    // Thread ti takes workgroups ti and ti + SYNC_WG (the grid is resident: fewer than 2 SYNC_WG of them).  A record's nine words are
-    // asked for together and looked at afterwards -- each says for itself whether it is there (value | call number << 32) -- and a
-    // thread polls until its records are whole: when the image's slowest workgroup publishes at last, the workgroups behind it have
-    // everything else in registers already and are one load away from their write loops.  (Round 2 waited for first words with
-    // one wavefront and 2 us of sleep between looks, then read every word through its own validation loop: eleven round trips one
-    // after the other, 25 us between the slowest K1 part's end and the K2 loops behind it.)
-    int4 f_sum = make_int4(0, 0, 0, 0);
-    uint32_t f_rec = 0;
-    int f_bad = gi >= 2 * SYNC_WG ? 2 : 0;
-    uint64_t xa = 0, xb = 0, asa = X_NONE, asb = X_NONE;   // last exit state and assumed entry state of the two workgroups this thread takes
-    {
-        const bool ha = ti < gi, hb = ti + SYNC_WG < gi && !f_bad;
-        bool oka = !ha || f_bad, okb = !hb;
-        auto load_rec = [&](uint32_t h, uint64_t& xe, uint64_t& as) -> bool {
-            const unsigned long long* pw = ka.pub + (size_t)h * PUB_WORDS;
-            unsigned long long v[PUB_WORDS];
-#pragma unroll
-            for (uint32_t q = 0; q < PUB_WORDS; ++q) v[q] = __hip_atomic_load(pw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool ok = true;
-#pragma unroll
-            for (uint32_t q = 0; q < PUB_WORDS; ++q) ok = ok && (uint32_t)(v[q] >> 32) == ka.gen;
-            if (ok) {
-                f_sum = add4(f_sum, make_int4((int)(uint32_t)v[0], (int)(uint32_t)v[1], (int)(uint32_t)v[2], (int)(uint32_t)v[3]));
-                f_rec += (uint32_t)v[4];
-                xe = (uint64_t)(uint32_t)v[5] | ((uint64_t)(uint32_t)v[6] << 32);
-                as = (uint64_t)(uint32_t)v[7] | ((uint64_t)(uint32_t)v[8] << 32);
-            }
-            return ok;
-        };
+    };
+    hand_over();
+    __builtin_amdgcn_s_setprio(0);
+    int f_bad = 0;
+    // ---- this workgroup's own assumption ----
+    // Its first own item decoded from the state its lead-in items arrived at; the state it had to start from is the last exit state of the
+    // workgroup before (final as published: a workgroup's last item has re-synchronised hundreds of items after its first, whatever that
+    // one started from).  Synthetic fields always match.  Photographs have, somewhere, a workgroup whose lead-in had not re-synchronised
+    // yet: that workgroup REPAIRS itself here -- K1's work once more as a later pass does it (the results loaded, the first item's entry
+    // state set right, the items it reaches decoded again) -- and publishes its totals a second time, in a record of their own.  (Round 2
+    // gave the whole call up to the three launches behind this kernel: 0.30 instead of 0.21 ms for an 8K photograph at 1.5 bit/px.)
+    if (ti == 0 && gi > 0) {
         SpinGuard guard(FUSED_SPIN_TICKS);
-        for (;;) {
-            if (!oka) oka = load_rec(ti, xa, asa);
-            if (!okb) okb = load_rec(ti + SYNC_WG, xb, asb);
-            if (!__ballot(!oka || !okb)) break;   // (wave-uniform: the wavefront polls until all its records are whole)
+        while ((uint32_t)(xq0 >> 32) != ka.gen || (uint32_t)(xq1 >> 32) != ka.gen) {
             if (guard.expired()) {
                 f_bad = 2;
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
+            xq0 = __hip_atomic_load(ka.pub + (size_t)(gi - 1) * PUB_WORDS + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xq1 = __hip_atomic_load(ka.pub + (size_t)(gi - 1) * PUB_WORDS + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_hx[2 * (SYNC_WG / 64)] = (uint64_t)(uint32_t)xq0 | ((uint64_t)(uint32_t)xq1 << 32);   // x_before
+    }
+    if (__syncthreads_or(f_bad)) {
+        if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const uint64_t x_before = gi > 0 ? s_hx[2 * (SYNC_WG / 64)] : 0ull;   // the exit state of the sub-sequence before this workgroup's first
+    if (gi > 0 && k1_as != X_NONE && k1_as != x_before) {   // (the same for every thread)
+        __builtin_amdgcn_s_setprio(KPEG_FUSED_PRIO);
+        {
+            const SyncArgs& a = ka;
+            const int p = 1;
+            const uint32_t g = blockIdx.x, t = threadIdx.x;
+            uint64_t* const Xb_cur = a.Xb;
+            const uint64_t* const Xb_prev = a.Xb;   // (what a later pass compares and counts for the launch behind it: nothing here)
+            const bool mute = false;
+            const uint64_t entry = x_before;
+#include "k1_wg_body.inc.h"
+            k1_exit = r.exit_state;
+            k1_cnt = r.cnt;
+            k1_nrec = r.nrec;
+            k1_wu = wu;
+            k1_own = have && t >= wu;
+        }
+        __syncthreads();
+        // the last exit state has been published and compared: it must stand (it does, unless the stream never re-synchronises inside
+        // a workgroup's 501 sub-sequences: the launches behind this kernel take such a call)
+        if (s_edge[1] != k1_last) {
+            if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (ti == 0) {
+            const int4 w = ka.wsum[gi];   // (this thread's own stores)
+            const uint32_t wr = ka.wrec[gi];
+            const uint32_t vals[PUB2_WORDS] = {(uint32_t)w.x, (uint32_t)w.y, (uint32_t)w.z, (uint32_t)w.w, wr};
+            unsigned long long* const p2 = ka.pub + (size_t)ka.nwg_cap * PUB_WORDS + (size_t)gi * PUB2_WORDS;
+            for (uint32_t q = 0; q < PUB2_WORDS; ++q)
+                __hip_atomic_store(p2 + q, (unsigned long long)vals[q] | ((unsigned long long)ka.gen << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&ka.meta->repaired, 1u);
+        }
+        hand_over();
+        __builtin_amdgcn_s_setprio(0);
+    }
+    // ---- every workgroup before this one: wait for what it published, add it up ----
+    // Thread ti takes workgroups ti, ti + SYNC_WG, ..., two at a time.  A record's nine words (and the two of the record before it that
+    // hold the exit state its assumption has to match) are asked for together and looked at afterwards -- each says for itself whether
+    // it is there (value | call number << 32) -- and a thread polls until its records are whole: when the image's slowest workgroup
+    // publishes at last, the workgroups behind it have everything else in registers already and are one load away from their write
+    // loops.  (Round 2 waited for first words with one wavefront and 2 us of sleep between looks, then read every word through its
+    // own validation loop: eleven round trips one after the other, 25 us between the slowest K1 part's end and the K2 loops behind it.)
+    // A workgroup whose assumption does not match the exit state before it (seen here as it sees it itself) repairs itself: its totals
+    // are taken from its second record, when that is there.
+    // The grid may be larger than what the device holds at once (photographs at 8K: 1000-2500 workgroups for 768 places).  A workgroup only
+    // ever waits for smaller indices; the dispatcher hands workgroups out in index order, so those are running or done -- and if a device
+    // did not, the waits expire (SpinGuard) and the launches behind this kernel decode the call: slower, never wrong, never hung.
+    int4 f_sum = make_int4(0, 0, 0, 0);
+    uint32_t f_rec = 0;
+    {
+        SpinGuard guard(FUSED_SPIN_TICKS);
+        auto load_rec = [&](uint32_t h, int4& sm, uint32_t& rc, bool& rep) -> bool {
+            const unsigned long long* pw = ka.pub + (size_t)h * PUB_WORDS;
+            unsigned long long v[PUB_WORDS], l0 = (unsigned long long)ka.gen << 32, l1 = l0;
+#pragma unroll
+            for (uint32_t q = 0; q < PUB_WORDS; ++q) v[q] = __hip_atomic_load(pw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h > 0) {
+                l0 = __hip_atomic_load(pw - PUB_WORDS + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                l1 = __hip_atomic_load(pw - PUB_WORDS + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool ok = (uint32_t)(l0 >> 32) == ka.gen && (uint32_t)(l1 >> 32) == ka.gen;
+#pragma unroll
+            for (uint32_t q = 0; q < PUB_WORDS; ++q) ok = ok && (uint32_t)(v[q] >> 32) == ka.gen;
+            if (ok) {
+                sm = make_int4((int)(uint32_t)v[0], (int)(uint32_t)v[1], (int)(uint32_t)v[2], (int)(uint32_t)v[3]);
+                rc = (uint32_t)v[4];
+                const uint64_t as = (uint64_t)(uint32_t)v[7] | ((uint64_t)(uint32_t)v[8] << 32), left = (uint64_t)(uint32_t)l0 | ((uint64_t)(uint32_t)l1 << 32);
+                rep = h > 0 && as != X_NONE && as != left;   // that workgroup has repaired itself (or is about to)
+            }
+            return ok;
+        };
+        auto load_rec2 = [&](uint32_t h, int4& sm, uint32_t& rc) -> bool {
+            const unsigned long long* pw = ka.pub + (size_t)ka.nwg_cap * PUB_WORDS + (size_t)h * PUB2_WORDS;
+            unsigned long long v[PUB2_WORDS];
+#pragma unroll
+            for (uint32_t q = 0; q < PUB2_WORDS; ++q) v[q] = __hip_atomic_load(pw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (uint32_t q = 0; q < PUB2_WORDS; ++q) ok = ok && (uint32_t)(v[q] >> 32) == ka.gen;
+            if (ok) {
+                sm = make_int4((int)(uint32_t)v[0], (int)(uint32_t)v[1], (int)(uint32_t)v[2], (int)(uint32_t)v[3]);
+                rc = (uint32_t)v[4];
+            }
+            return ok;
+        };
+        for (uint32_t h0 = ti; h0 < gi && !f_bad; h0 += 2 * SYNC_WG) {
+            const bool hb = h0 + SYNC_WG < gi;
+            int4 sum_a = make_int4(0, 0, 0, 0), sum_b = make_int4(0, 0, 0, 0);
+            uint32_t rec_a = 0, rec_b = 0;
+            bool oka = false, okb = !hb, rep_a = false, rep_b = false;
+            for (;;) {
+                if (!oka) oka = load_rec(h0, sum_a, rec_a, rep_a);
+                if (!okb) okb = load_rec(h0 + SYNC_WG, sum_b, rec_b, rep_b);
+                if (oka && okb) break;
+                if (guard.expired()) {
+                    f_bad = 2;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            while ((rep_a || rep_b) && !f_bad) {
+                if (rep_a) rep_a = !load_rec2(h0, sum_a, rec_a);
+                if (rep_b) rep_b = !load_rec2(h0 + SYNC_WG, sum_b, rec_b);
+                if (!(rep_a || rep_b)) break;
+                if (guard.expired() || __hip_atomic_load(&ka.meta->fused_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ka.gen) {   // (or that workgroup gave the call up)
+                    f_bad = 2;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            f_sum = add4(f_sum, add4(sum_a, sum_b));
+            f_rec += rec_a + rec_b;
         }
     }
 #if KPEG_SYNC_STATS
     const uint64_t tw1 = __builtin_amdgcn_s_memtime();   // this wavefront has every record it takes
 #endif
-    // the exit state each assumption has to match is the workgroup's before: one lane over, one wavefront over (through LDS), and for
-    // workgroup SYNC_WG the last of the first round's
     {
         const uint32_t lane = ti & 63, wave = ti >> 6;
-        if (lane == 63) {
-            s_hx[wave] = xa;
-            s_hx[SYNC_WG / 64 + wave] = xb;
-        }
         f_sum = make_int4(wave_scan_incl(f_sum.x), wave_scan_incl(f_sum.y), wave_scan_incl(f_sum.z), wave_scan_incl(f_sum.w));
         f_rec = wave_scan_incl(f_rec);
         if (lane == 63) {
             s_hsum[wave] = f_sum;
             s_hrec[wave] = f_rec;
         }
-        if (gi > 0 && ((gi - 1) % SYNC_WG) == ti) s_hx[2 * (SYNC_WG / 64)] = gi - 1 < (uint32_t)SYNC_WG ? xa : xb;   // x_before
-        __syncthreads();
-        const uint64_t la = (uint64_t)wave_shr1((uint32_t)xa) | ((uint64_t)wave_shr1((uint32_t)(xa >> 32)) << 32);
-        const uint64_t lb = (uint64_t)wave_shr1((uint32_t)xb) | ((uint64_t)wave_shr1((uint32_t)(xb >> 32)) << 32);
-        const uint64_t left_a = lane ? la : (wave ? s_hx[wave - 1] : 0ull);
-        const uint64_t left_b = lane ? lb : (wave ? s_hx[SYNC_WG / 64 + wave - 1] : s_hx[SYNC_WG / 64 - 1]);
-        if (ti >= 1 && ti < gi && asa != X_NONE && asa != left_a) f_bad |= 1;
-        if (ti + SYNC_WG < gi && asb != X_NONE && asb != left_b) f_bad |= 1;
     }
-    const uint64_t x_before = gi > 0 ? s_hx[2 * (SYNC_WG / 64)] : 0ull;   // the exit state of the sub-sequence before this workgroup's first
-    if (ti == 0 && gi > 0 && k1_as != X_NONE && k1_as != x_before) f_bad |= 1;   // this workgroup's own assumption
     if (__syncthreads_or(f_bad)) {
         if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -1980,10 +2080,10 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     // at once unless it gave up.
     bool fuse = false;
     if constexpr (SB < SUBSEQ_DENSE) {
-        fuse = stuffed && L.d_tile_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= L.fused_slots;
+        fuse = stuffed && L.d_tile_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= FUSED_MAX_WG;
         if (fuse) {
             const size_t cap_before = S->flags_cap;
-            if ((rc = ent_grow(&S->d_flags, &S->flags_cap, (size_t)nwg_cap * PUB_WORDS * sizeof(unsigned long long), L.stream, err))) return rc;
+            if ((rc = ent_grow(&S->d_flags, &S->flags_cap, (size_t)nwg_cap * (PUB_WORDS + PUB2_WORDS) * sizeof(unsigned long long), L.stream, err))) return rc;
             bool wipe = S->flags_cap != cap_before;   // (a new allocation -- even at the old address -- holds anything)
             if (++S->gen == 0) {
                 ++S->gen;   // 0 is "not that path"

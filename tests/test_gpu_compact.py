@@ -3,6 +3,9 @@ first record of every tile) against the oracle, and against the dense int16 layo
 
 The library picks the layout per call (sparse streams whose width is a multiple of 64); the test hook
 kpeg_hip_debug_set(ctx, 7, layout) forces 1 = dense or 2 = compact wherever the geometry allows."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -206,3 +209,45 @@ def test_huge_blocks_split_over_lanes_and_workgroups_after_another_picture(ctx):
     finally:
         ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)
         ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+
+
+@pytest.mark.parametrize("warm", [0, 1, 3])
+def test_workgroups_whose_entry_state_is_wrong_repair_themselves(ctx, warm):
+    """k_sync_write with K1's lead-in cut to 0, 1 or 3 sub-sequences (debug key 2): nearly every workgroup then starts its first
+    own sub-sequence from a state that is not the one the workgroup before ends in.  Each must find that out from its
+    predecessor's published exit state, decode again from the right one as far as the change reaches, publish its totals a
+    second time, and its successors must take those: the call is finished by that kernel alone (one launch of K1 with work)
+    and every pixel is the oracle's.  Synthetic field (short re-synchronisation) and a photograph (long)."""
+    import libkpeg_amd as K
+    cases = [("synthetic 2048x1024", T.synth_jpeg(2048, 1024, seed=5, quality=75, sigma=6.0))]
+    try:
+        import PIL  # noqa: F401
+        sys.path.insert(0, T.ROOT)
+        import bench
+        cases.append(("lena tiled to 2048x1024, q50", bench.tiled_photo_jpeg("lena.jpg", 50, 2048, 1024)))
+        cases.append(("lena tiled to 2048x1024, q75", bench.tiled_photo_jpeg("lena.jpg", 75, 2048, 1024)))
+    except ImportError:
+        pass
+    try:
+        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 2, warm) == 0
+        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 2) == 0   # the compact stream (these pictures are below the size that takes it by itself)
+        for what, data in cases:
+            st, want = T.oracle_decode(data)
+            assert st == T.DECODE_DONE
+            rc, frame, scan = K.host_parse(data)
+            assert rc == K.DECODE_DONE
+            for fused in (1, 0):
+                assert ctx.lib.kpeg_hip_debug_set(ctx._h, 9, fused) == 0
+                for rep in range(2):
+                    ctx.set_profiling(True)
+                    got = ctx.decode_scan(frame, scan)
+                    rounds = int(ctx.timings()["sync_rounds"])
+                    ctx.set_profiling(False)
+                    bad = np.argwhere(got != want)
+                    assert bad.size == 0, "%s warm %d fused %d: first mismatches (y,x,c) %s of %d" % (what, warm, fused, bad[:8].tolist(), len(bad))
+                    if fused and len(scan) * 8 < 2.5 * frame.width * frame.height and len(scan) > 8 * 501 * 12:
+                        assert rounds == 1, "%s warm %d: k_sync_write did not finish this call itself (%d launches of K1 had work)" % (what, warm, rounds)
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 2, -1)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)

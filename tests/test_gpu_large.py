@@ -69,7 +69,9 @@ def test_photographs_match_the_reference_ppm(ctx, name):
 def test_photographs_tiled_to_8k_match_the_reference(ctx, key):
     """The natural-content inputs of bench.py's default line (committed photographs tiled to 7680 x 4352, 1.0-3.5 bits per pixel):
     pixels against libKPEG's own decoder (tests/golden/make_golden_photos.py), with k_sync_write and through the separate
-    launches.  On these the one-kernel path usually hands on (some workgroup's entry assumption fails)."""
+    launches.  On these some workgroup's entry assumption always fails and the grid is larger than what the device holds at
+    once (1000-1400 workgroups): k_sync_write's workgroups repair themselves, and the launches behind it have nothing to do
+    (one launch of K1 with work) wherever the bit rate takes the 96-bit sub-sequences the kernel exists for."""
     import sys
     pytest.importorskip("PIL")
     sys.path.insert(0, T.ROOT)
@@ -83,8 +85,13 @@ def test_photographs_tiled_to_8k_match_the_reference(ctx, key):
     try:
         for fused in (1, 0):
             assert ctx.lib.kpeg_hip_debug_set(ctx._h, 9, fused) == 0
+            ctx.set_profiling(True)
             rgb = ctx.decode_scan(frame, scan)
+            rounds = int(ctx.timings()["sync_rounds"])
+            ctx.set_profiling(False)
             assert sha(rgb.tobytes()) == g["rgb_sha256"], fused
+            if fused and len(scan) * 8 / (frame.width * frame.height) < 2.5:
+                assert rounds == 1, rounds
     finally:
         ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)
 

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""tools/photo_breakdown.py -- where the time of the bench's photographs goes (GPU box): per-kernel HIP-event times of one
+decode of each of bench.PHOTO_CASES at 7680x4352, with the bit rate's own sub-sequence size and with the others forced."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import bench
+import libkpeg_amd as K
+
+torch.cuda.set_stream(torch.cuda.Stream())
+ctx = K.Context(0)
+ctx.set_profiling(True)
+sizes = [int(a) for a in sys.argv[1:]] or [0]
+for (src, q) in bench.PHOTO_CASES:
+    data = bench.tiled_photo_jpeg(src, q)
+    rc, f, scan = K.host_parse(data)
+    bpp = len(scan) * 8 / (f.width * f.height)
+    for sb in sizes:
+        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, sb) == 0
+        best = None
+        for _ in range(5):
+            ctx.decode_scan(f, scan)
+            t = ctx.timings()
+            if best is None or t["total_ms"] < best["total_ms"]:
+                best = dict(t)
+        print("%-28s q%d %.2f bits/px  sub-sequence %3s: %s" % (src, q, bpp, sb or "own", "  ".join("%s=%.4f" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in best.items())), flush=True)
