@@ -82,11 +82,15 @@ constexpr int SYNC_PASSES = 3;   // sync kernels enqueued per call: pass 0, the 
 #define KPEG_WARM_BITS 1024
 #endif
 constexpr int WARM_BITS = KPEG_WARM_BITS;  // a workgroup decodes this much of its predecessor's tail to find its own entry state
+// ... and twice that with the dense sub-sequences: streams that take those re-synchronise slowly, and three 384-bit items were too
+// short a lead-in for an 8K photograph at 3.5 bit/px (K1 0.278 -> 0.244 ms with six, profiles/r03_e; the 96-bit path does not care:
+// 11 or 22 or 43 items, the same time on synthetic fields and on photographs)
+constexpr int WARM_BITS_DENSE = 2 * KPEG_WARM_BITS;
 constexpr int ITEMS = SYNC_WG;
 // the geometry that follows from the sub-sequence size S, as local constants of the code templated on S
 #define KPEG_GEOMETRY(S)                                                                                                  \
     constexpr int SUBSEQ_BITS = (S), SUBSEQ_WORDS = (S) / 32;                                                             \
-    constexpr int WARM = (WARM_BITS + (S) - 1) / (S); /* warm-up sub-sequences */                                         \
+    constexpr int WARM = (((S) >= SUBSEQ_DENSE && SUBSEQ_DENSE > SUBSEQ_SPARSE ? WARM_BITS_DENSE : WARM_BITS) + (S) - 1) / (S); /* warm-up sub-sequences */ \
     constexpr int OWN = SYNC_WG - WARM; /* sub-sequences per workgroup: with the warm-up ones a thread each */            \
     static_assert(OWN >= WARM && OWN >= 64, "workgroup too small for the warm-up distance");                              \
     static_assert((S) >= 64 && (S) % 32 == 0, "a symbol (<= 31 bits) must not jump over a whole sub-sequence");          \

@@ -4,8 +4,12 @@ when K1's part ends, when K2's loop starts and ends, on the workgroup's own cloc
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch, libkpeg_amd as K, bench
-W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (7680, 4320)
-data = bench.synth_jpeg(W, H)
+# python tools/fused_timeline.py [W H]  |  python tools/fused_timeline.py photo lena.jpg 75   (a committed photograph tiled to 7680x4352)
+if len(sys.argv) > 3 and sys.argv[1] == "photo":
+    data = bench.tiled_photo_jpeg(sys.argv[2], int(sys.argv[3]))
+else:
+    W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (7680, 4320)
+    data = bench.synth_jpeg(W, H)
 rc, frame, scan = K.host_parse(data)
 ctx = K.Context(0)
 ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 2)
