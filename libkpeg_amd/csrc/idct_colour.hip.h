@@ -613,9 +613,7 @@ constexpr int ROWQ_WORDS = 20;    // per row: [0, 12) [component][pixel column] 
 struct FxArgs {   // what fx_flush needs of IdctParams, by value (a reference to the kernel's arguments would put them on the stack)
     uint8_t* rgb;
     uint8_t* const* rgb_table;
-    const int16_t* coef;
-    const float* ebound;
-    uint32_t pitch, tiles_w, tiles_w_magic, tiles_w_shift, mcus_w, ntiles, rows_per_img;
+    uint32_t pitch, tiles_w, tiles_w_magic, tiles_w_shift, ntiles, rows_per_img;
 };
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 typedef __attribute__((address_space(3))) const double lds_cf64;
@@ -755,8 +753,8 @@ __device__ KPEG_FX_MANY_ATTR void fx_noncorner_many(lds_u32* entry, lds_cu32* im
     fx_vouch(entry, vouch);
 }
 
-// q: the wavefront's queue, nrows entries; s_qi: [2][64] quantisers, natural order.
-template <bool COMPACT>
+// q: the wavefront's queue, nrows entries; s_qi: [2][64] quantisers, natural order.  Reads LDS only (an entry carries all it takes);
+// what is still unsafe in an entry belongs to a corner-only block (fx_noncorner_* have settled the rest).
 __device__ __attribute__((noinline)) void fx_flush(FxArgs a, lds_cu32* q, uint32_t nrows, lds_cu32* s_qi, lds_cf64* s_cos)
 {
     const uint32_t lane = (uint32_t)__lane_id();
@@ -770,29 +768,15 @@ __device__ __attribute__((noinline)) void fx_flush(FxArgs a, lds_cu32* q, uint32
         for (int k = 0; k < 12; ++k) hs[k] = have ? e[k] : 0u;
         if (have) {
             keys = e[12], where = e[13];
-            if constexpr (COMPACT) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) cw[k] = e[14 + k];
-            }
+            for (int k = 0; k < 6; ++k) cw[k] = e[14 + k];
         }
     }
     const uint32_t tile = min(where >> 6, a.ntiles - 1), Lt = where & 63u;
     const uint32_t g = Lt >> 3, x = Lt & 7u;   // MCU of the tile, pixel row
     const uint32_t trow = a.tiles_w == 1 ? tile : (__umulhi(tile, a.tiles_w_magic) >> a.tiles_w_shift), tcol = tile - trow * a.tiles_w;
     const uint32_t m0 = tcol * TILE_MCUS;
-    const size_t mcu = (size_t)trow * a.mcus_w + m0 + g;
     uint32_t todo = have ? ~(keys & (keys >> 8) & (keys >> 16) & (keys >> 24)) & 0xFFu : 0u;   // bit 7 - i: pixel column i is marked
-    // dense layout: which blocks are corner-only (the bounds' signs), and those blocks' two words
-    uint32_t crn = 7u;   // compact stream: what is still unsafe in an entry is corner-only (fx_noncorner has settled the rest)
-    if constexpr (!COMPACT) {
-        if (todo) {
-            struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
-            const F3 eb = *reinterpret_cast<const F3*>(a.ebound + mcu * 3);
-            crn = (__float_as_int(eb.a) < 0 ? 1u : 0u) | (__float_as_int(eb.b) < 0 ? 2u : 0u) | (__float_as_int(eb.c) < 0 ? 4u : 0u);
-            const uint32_t* c32 = reinterpret_cast<const uint32_t*>(a.coef) + mcu * 96;   // block c at + 32 c words
-            cw[0] = c32[0], cw[1] = c32[4], cw[2] = c32[32], cw[3] = c32[36], cw[4] = c32[64], cw[5] = c32[68];
-        }
-    }
     // the pixel's bytes in the picture
     size_t rowoff;
     {
@@ -828,39 +812,16 @@ __device__ __attribute__((noinline)) void fx_flush(FxArgs a, lds_cu32* q, uint32
         for (int c = 0; c < 3; ++c) {
             if (!(need & (1u << c))) continue;
             lds_cu32* qi = s_qi + (c ? 64 : 0);
-            if (COMPACT || (crn & (1u << c))) {
-                // MCU::computeIDCT's sum (MCU.cpp:184-198) for a block that has nothing outside (0,0), (0,1), (1,0), (1,1), in its order; a
-                // zero term leaves the float accumulator as it is (x + (+-0) == x), so none needs a test.  cos((2x+1) 0 pi/16) == 1.0 exactly.
-                const uint32_t wa = cw[2 * c], wb = cw[2 * c + 1];
-                const float fc00 = (c0 * c0) * (float)((int)(short)(wa & 0xFFFF) * (int)qi[0]), fc01 = (c0 * 1.0f) * (float)(((int)wa >> 16) * (int)qi[1]),
-                            fc10 = (1.0f * c0) * (float)((int)(short)(wb & 0xFFFF) * (int)qi[8]), fc11 = (float)(((int)wb >> 16) * (int)qi[9]);
-                float sum = fc00;
-                sum = (float)((double)sum + (double)fc01 * cy[1]);
-                sum = (float)((double)sum + (double)fc10 * cx[1]);
-                sum = (float)((double)sum + ((double)fc11 * cx[1]) * cy[1]);
-                S[c] = level_shift((float)(0.25 * (double)sum));
-            } else {
-                // the 64-term sum in the reference's order, zero coefficients skipped (they leave the float accumulator unchanged)
-                const uint4* blk = reinterpret_cast<const uint4*>(a.coef) + (mcu * 3 + c) * 8;
-                float sum = 0.0f;
-                for (int uu = 0; uu < 8; ++uu) {
-                    const uint4 d = blk[uu];
-                    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
-                    const double cxu = cx[uu];
-                    const float cu = uu == 0 ? c0 : 1.0f;
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) {
-                        const int cf = (v & 1) ? ((int)w[v >> 1] >> 16) : (int)(short)(w[v >> 1] & 0xFFFF);
-                        if (cf != 0) {
-                            const int F = cf * (int)qi[uu * 8 + v];                     // m_8x8block after MCU.cpp:110-112
-                            const float fc = (cu * (v == 0 ? c0 : 1.0f)) * (float)F;    // Cf[u] * Cf[v] in float, float multiply (MCU.cpp:189-192)
-                            const double t = ((double)fc * cxu) * cy[v];
-                            sum = (float)((double)sum + t);
-                        }
-                    }
-                }
-                S[c] = level_shift((float)(0.25 * (double)sum));
-            }
+            // MCU::computeIDCT's sum (MCU.cpp:184-198) for a block that has nothing outside (0,0), (0,1), (1,0), (1,1), in its order; a
+            // zero term leaves the float accumulator as it is (x + (+-0) == x), so none needs a test.  cos((2x+1) 0 pi/16) == 1.0 exactly.
+            const uint32_t wa = cw[2 * c], wb = cw[2 * c + 1];
+            const float fc00 = (c0 * c0) * (float)((int)(short)(wa & 0xFFFF) * (int)qi[0]), fc01 = (c0 * 1.0f) * (float)(((int)wa >> 16) * (int)qi[1]),
+                        fc10 = (1.0f * c0) * (float)((int)(short)(wb & 0xFFFF) * (int)qi[8]), fc11 = (float)(((int)wb >> 16) * (int)qi[9]);
+            float sum = fc00;
+            sum = (float)((double)sum + (double)fc01 * cy[1]);
+            sum = (float)((double)sum + (double)fc10 * cx[1]);
+            sum = (float)((double)sum + ((double)fc11 * cx[1]) * cy[1]);
+            S[c] = level_shift((float)(0.25 * (double)sum));
         }
         if (act) {
             const uint32_t px = colour_exact(S[0], S[1], S[2]);
@@ -902,7 +863,7 @@ template <bool COMPACT>
 __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(IdctParams p, QTables qt)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_all[K4_WAVES][8 * TILE_ROW_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_img_all[COMPACT ? K4_WAVES : 1][IMG_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_img_all[K4_WAVES][IMG_BYTES / 4];   // the tile's 24 blocks, natural order, int16 (compact stream: rebuilt from the records; dense layout: the rows as loaded)
     __shared__ __attribute__((aligned(16))) float s_m[2][64];     // AC input scales, natural order
     __shared__ uint32_t s_next;       // next tile of this workgroup's range to hand out
     __shared__ __attribute__((aligned(16))) uint32_t s_rowq_all[K4_WAVES][ROWQ_CAP * ROWQ_WORDS];   // the wavefronts' queues of pixel rows that have a marked pixel
@@ -923,7 +884,7 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
     const int tid = threadIdx.x & 63;   // lane of the wavefront
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint8_t* const s_tile = s_tile_all[wave];
-    uint32_t* const s_img = s_img_all[COMPACT ? wave : 0];
+    uint32_t* const s_img = s_img_all[wave];
     const int lane8 = tid & 7;          // lane within the MCU group = output pixel row
     const int grp = tid >> 3;           // MCU within the tile, 0..7
     const int u = lane8 < 4 ? 2 * lane8 : 2 * (lane8 - 4) + 1;  // coefficient row this lane loads
@@ -985,9 +946,9 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const FxArgs fa = {p.rgb, p.rgb_table, p.coef, p.ebound, p.pitch, p.tiles_w, p.tiles_w_magic, p.tiles_w_shift, p.mcus_w, p.ntiles, p.rows_per_img};
+        const FxArgs fa = {p.rgb, p.rgb_table, p.pitch, p.tiles_w, p.tiles_w_magic, p.tiles_w_shift, p.ntiles, p.rows_per_img};
 #ifndef KPEG_FX_NO_FLUSH
-        fx_flush<COMPACT>(fa, (lds_cu32*)s_rowq, qcount, (lds_cu32*)s_qi, (lds_cf64*)s_cos);
+        fx_flush(fa, (lds_cu32*)s_rowq, qcount, (lds_cu32*)s_qi, (lds_cf64*)s_cos);
 #endif
         qcount = 0;
         KPEG_STAMP_END(stamp_flush, stamp_nflush)
@@ -1156,6 +1117,11 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             d0 = rows[0], d1 = rows[8], d2 = rows[16];
         } else {
             d0 = cur.d0, d1 = cur.d1, d2 = cur.d2;
+            // the rows as loaded also go to the tile's image in LDS (three 16-byte stores per lane): what settles the marked pixels
+            // reads the blocks there, as it does with the compact stream (round 3's first build read them again from memory, one lane
+            // per pixel row: dense content -- noise, photographs at high quality -- took K4 10-30 % longer than round 2's)
+            uint4* rows = reinterpret_cast<uint4*>(s_img) + (grp * 3) * 8 + u;
+            rows[0] = d0, rows[8] = d1, rows[16] = d2;
         }
         const float e0 = cur.e0, e1 = cur.e1, e2 = cur.e2;
         if constexpr (PREFETCH) {
@@ -1304,7 +1270,7 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
                         const uint4v h0 = {hp[0][0], hp[0][1], hp[0][2], hp[0][3]}, h1 = {hp[1][0], hp[1][1], hp[1][2], hp[1][3]}, h2 = {hp[2][0], hp[2][1], hp[2][2], hp[2][3]};
                         uint4v h3 = {(ubY & 0xFFu) | ((ubB & 0xFFu) << 8) | ((ubR & 0xFFu) << 16) | (ubG << 24), (tile << 6) | (uint32_t)tid, 0u, 0u};
                         uint4v h4 = {0u, 0u, 0u, 0u};
-                        if constexpr (COMPACT) {
+                        {
                             uint32_t gl = (uint32_t)tid;
                             asm volatile("" : "+v"(gl));   // (worked out here, not kept in a register across the loop)
                             const uint32_t* b32 = s_img + (gl >> 3) * 3 * 32;   // the MCU's three blocks, 32 words each
@@ -1316,7 +1282,7 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
                         row[0] = h0, row[1] = h1, row[2] = h2, row[3] = h3, row[4] = h4;
                     }
                     qcount += nrow;
-                    if constexpr (COMPACT) {
+                    {
 #if defined(KPEG_COUNT_NC)
                         fx_lane += (uint32_t)__popc(nc);
 #elif defined(KPEG_COUNT_NCTILES)

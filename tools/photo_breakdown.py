@@ -11,6 +11,9 @@ import libkpeg_amd as K
 torch.cuda.set_stream(torch.cuda.Stream())
 ctx = K.Context(0)
 ctx.set_profiling(True)
+import os
+if os.environ.get("KPEG_IDCT_MODE"):
+    ctx.set_idct_mode(int(os.environ["KPEG_IDCT_MODE"]))   # 2: marked pixels are counted, not settled (wrong pixels: what K4's tile loop alone costs)
 sizes = [int(a) for a in sys.argv[1:]] or [0]
 for (src, q) in bench.PHOTO_CASES:
     data = bench.tiled_photo_jpeg(src, q)

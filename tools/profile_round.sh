@@ -11,14 +11,15 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 tail -1 $out/bench.json
 python3 bench.py --side-figures --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_side_figures.json
 python3 bench.py --batch 256 --steps 5 --warmup 2 2>/dev/null | tail -1 > $out/bench_batch256.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --no-cpu-baseline --steps 40 --warmup 3 > $out/stats.log 2>&1
+python3 bench.py --image16k --steps 5 --warmup 2 2>/dev/null | tail -1 > $out/bench_image16k.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --no-cpu-baseline --no-photographs --steps 40 --warmup 3 > $out/stats.log 2>&1
 f=$(ls $out/stats/*kernel_stats.csv $out/stats/*/*kernel_stats.csv 2>/dev/null | head -1)
 cp "$f" $out/kernel_stats.csv
 rm -rf $out/stats
 head -12 $out/kernel_stats.csv
 # HBM traffic of K4 on the SAME command the bench line comes from (the whole decode, not K4 alone): separate passes per counter
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || true
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-photographs > $out/pmc_$c.log 2>&1 || true
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
