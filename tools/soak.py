@@ -41,6 +41,7 @@ def main():
                     p = T.oracle_parse(data)
                 frame, scan = T.make_frame(p, ri), p.scan
                 ctx.lib.kpeg_hip_debug_set(ctx._h, 7, int(rng.choice([0, 1, 2])))
+                ctx.lib.kpeg_hip_debug_set(ctx._h, 2, int(rng.choice([-1, -1, 0, 1, 3])))   # K1's lead-in: cut short, k_sync_write's workgroups repair themselves
             else:
                 w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
                 if kind == "gray":      # the grayscale oracle wants whole blocks
@@ -83,6 +84,7 @@ def main():
             continue
         finally:
             ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+            ctx.lib.kpeg_hip_debug_set(ctx._h, 2, -1)
         n += 1
         kinds[kind] = kinds.get(kind, 0) + 1
         if not np.array_equal(got, want):
