@@ -525,7 +525,12 @@ static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t 
     // 91 / 93, 3840x2160 (48 MiB) 111 / 108, 7680x4320 (190 MiB) 220 / 199, 16384x16384 2050 / 1270, 256 x 1080p 141 -> 207
     // Gpixel/s: the dense layout's 2-byte scatter and its clear cost K2 and K1 more than the rebuild in LDS costs K4 once the
     // image is large enough for those to show beside the kernels' fixed latencies.
-    return !dense && nmcu * 384 > ((uint64_t)32 << 20);
+    // Dense streams (the 384-bit sub-sequences) too, up to 5 bits per pixel: an 8K photograph at 3.5 bit/px has ~25 non-zero terms
+    // per block -- 100 bytes of records against 128 + 128 (clear) of dense coefficients -- and K2's consecutive 4-byte records cost
+    // it 0.174 ms where the scattered 2-byte stores cost 0.223 (K4 0.127 against 0.110: the rebuild in LDS grows with the records);
+    // the whole decode 0.591 -> 0.556 ms (round 3, profiles/r03_e).  Beyond that the records outgrow the blocks.
+    if (nmcu * 384 <= ((uint64_t)32 << 20)) return false;
+    return !dense || scan_bytes * 8 < nmcu * 64 * 5;
 }
 
 static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint32_t nmcu,
