@@ -303,7 +303,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
 constexpr unsigned long long K0_SPIN_TICKS = 50000ull;        // 0.5 ms (a predecessor's 8 KiB take microseconds), then the fallback
 constexpr unsigned long long K1_SPIN_TICKS = 2000000000ull;   // 20 s: a predecessor's wait includes the whole chain before it
 constexpr uint32_t FUSED_MAX_WG = 4096;   // k_sync_write: every workgroup reads every record before its own -- 8 M records at this size, a few per cent of such a call's time
-constexpr unsigned long long FUSED_SPIN_TICKS = 30000ull;     // 0.3 ms (three times what the kernel takes on an 8K image): k_sync_write's waits; then the launches behind it take over
+constexpr unsigned long long FUSED_SPIN_TICKS = 30000ull, FUSED_SPIN_TICKS_DENSE = 100000ull;     // 0.3 ms (three times what the kernel takes on an 8K image; 1 ms with the long sub-sequences, whose workgroups take four times as long): k_sync_write's waits; then the launches behind it take over
 struct SpinGuard {
     unsigned long long t0 = 0, limit;
     uint32_t polls = 0;
@@ -1747,7 +1747,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     // state set right, the items it reaches decoded again) -- and publishes its totals a second time, in a record of their own.  (Round 2
     // gave the whole call up to the three launches behind this kernel: 0.30 instead of 0.21 ms for an 8K photograph at 1.5 bit/px.)
     if (ti == 0 && gi > 0) {
-        SpinGuard guard(FUSED_SPIN_TICKS);
+        SpinGuard guard(S >= SUBSEQ_DENSE && SUBSEQ_DENSE > SUBSEQ_SPARSE ? FUSED_SPIN_TICKS_DENSE : FUSED_SPIN_TICKS);
         while ((uint32_t)(xq0 >> 32) != ka.gen || (uint32_t)(xq1 >> 32) != ka.gen) {
             if (guard.expired()) {
                 f_bad = 2;
@@ -1815,7 +1815,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     int4 f_sum = make_int4(0, 0, 0, 0);
     uint32_t f_rec = 0;
     {
-        SpinGuard guard(FUSED_SPIN_TICKS);
+        SpinGuard guard(S >= SUBSEQ_DENSE && SUBSEQ_DENSE > SUBSEQ_SPARSE ? FUSED_SPIN_TICKS_DENSE : FUSED_SPIN_TICKS);
         auto load_rec = [&](uint32_t h, int4& sm, uint32_t& rc, bool& rep) -> bool {
             const unsigned long long* pw = ka.pub + (size_t)h * PUB_WORDS;
             unsigned long long v[PUB_WORDS], l0 = (unsigned long long)ka.gen << 32, l1 = l0;
@@ -2088,7 +2088,13 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     // One kernel for K1's pass 0 and K2 (k_sync_write) where it applies; the launches below follow it in any case and leave
     // at once unless it gave up.
     bool fuse = false;
+    // (both sub-sequence sizes since round 3: with the long ones an 8K photograph at 3-4 bit/px saves the verifying launch's second
+    // decode and K2's prologue, 1-4 % of the call: profiles/r03_e)
+#ifdef KPEG_NO_FUSE_DENSE
     if constexpr (SB < SUBSEQ_DENSE) {
+#else
+    if constexpr (true) {
+#endif
         fuse = stuffed && L.d_tile_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= FUSED_MAX_WG;
         if (fuse) {
             const size_t cap_before = S->flags_cap;
@@ -2134,7 +2140,10 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
 static bool entropy_dense_subseq(int forced, bool sub420, uint64_t bytes, uint64_t nmcu)
 {
     const uint64_t bits = bytes * 8, px = nmcu * 64;
-    return forced ? forced >= SUBSEQ_DENSE : (sub420 || bits >= px * 4 || (bits >= px * 3 && px >= (4u << 20)));
+    // (... and from 2.25 bits per pixel where the short sub-sequences would make more than 1.5 times the workgroups the device holds at
+    // once -- 6.9 MB of scan: the one kernel then runs in three and more generations, each as long as its slowest chain; 8K photographs,
+    // round 3: 2.04 bit/px 0.397 / 0.400 ms short / long, 2.87 bit/px 0.547 / 0.410, 3.04 bit/px 0.611 / 0.529)
+    return forced ? forced >= SUBSEQ_DENSE : (sub420 || bits >= px * 4 || (bits >= px * 3 && px >= (4u << 20)) || (bits * 4 >= px * 9 && bytes > 6900000u));
 }
 
 static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, const EntropyLaunch& L, hipEvent_t* ev, bool* ev_rec,

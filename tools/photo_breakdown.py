@@ -15,7 +15,10 @@ import os
 if os.environ.get("KPEG_IDCT_MODE"):
     ctx.set_idct_mode(int(os.environ["KPEG_IDCT_MODE"]))   # 2: marked pixels are counted, not settled (wrong pixels: what K4's tile loop alone costs)
 sizes = [int(a) for a in sys.argv[1:]] or [0]
-for (src, q) in bench.PHOTO_CASES:
+cases = list(bench.PHOTO_CASES)
+if os.environ.get("KPEG_MORE_PHOTOS"):   # the bit rates between the bench's cases
+    cases += [("lena.jpg", 85), ("lena.jpg", 90), ("lena.jpg", 93), ("nat_china_640x424_q90.jpg", 85), ("nat_china_640x424_q90.jpg", 93)]
+for (src, q) in cases:
     data = bench.tiled_photo_jpeg(src, q)
     rc, f, scan = K.host_parse(data)
     bpp = len(scan) * 8 / (f.width * f.height)
