@@ -82,13 +82,13 @@ constexpr int SYNC_PASSES = 3;   // sync kernels enqueued per call: pass 0, the 
 #define KPEG_WARM_BITS 1024
 #endif
 constexpr int WARM_BITS = KPEG_WARM_BITS;  // a workgroup decodes this much of its predecessor's tail to find its own entry state
-// ... and twice that with the dense sub-sequences: streams that take those re-synchronise slowly, and three 384-bit items were too
-// short a lead-in for an 8K photograph at 3.5 bit/px (K1 0.278 -> 0.244 ms with six, profiles/r03_e; a 4K field at 11 bit/px 0.227 ->
-// 0.184 ms; the 96-bit path does not care: 11 or 22 or 43 items, the same time on synthetic fields and on photographs).  The one input
-// that pays is the q95-noise stress figure, 1.25 -> 1.55 ms -- not for the lead-in's length (three items used of six compiled: the
-// same), but for 506 own items per workgroup instead of 509; not understood, and natural content was given the preference.
+// The dense sub-sequences have their own figure (KPEG_WARM_BITS_DENSE) because it was measured separately, and is the same 1024 bits
+// = three items: round 3 had six for a while (separate launches: an 8K photograph at 3.5 bit/px 0.278 -> 0.244 ms in K1, a 4K field
+// at 11 bit/px 0.227 -> 0.184) until those streams took k_sync_write, whose workgroups repair a wrong entry state themselves --
+// photographs at 2.9-3.8 bit/px then measure the same with three or six (+-5 % either way), the 4K field loses 10 % and the q95-noise
+// stress figure gains 19 % (1.68 -> 1.36 ms: not the lead-in's length but 509 own items per workgroup instead of 506; not understood).
 #ifndef KPEG_WARM_BITS_DENSE
-#define KPEG_WARM_BITS_DENSE (2 * KPEG_WARM_BITS)
+#define KPEG_WARM_BITS_DENSE KPEG_WARM_BITS
 #endif
 constexpr int WARM_BITS_DENSE = KPEG_WARM_BITS_DENSE;
 constexpr int ITEMS = SYNC_WG;
