@@ -1267,7 +1267,7 @@ struct SyncArgs {
     int pass;
     uint32_t* status;   // [1]: error flags (a chained wait that timed out); KPEG_SYNC_STATS builds: words 8..13 collect loop counts
     unsigned long long spin_ticks;   // bound of the chained pass's wait for the predecessor (SpinGuard)
-    uint32_t fault;     // test hook: bit 1 = workgroup 0 of a rippling chained pass never publishes
+    uint32_t fault;     // test hook: bit 1 = workgroup 0 of a rippling chained pass never publishes; bit 3 = every third workgroup of k_sync_write gives the call up
     uint32_t gray;      // one-component stream (extension): see run_count; the chroma blocks' bounds are preset to "exact"
     const uint8_t* scan;   // non-null: no K0 ran -- the sub-sequences are chunks of the byte-stuffed scan (stage_unstuff), nsub = nsub_host
     uint32_t scan_len;
@@ -1891,6 +1891,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             s_hrec[wave] = f_rec;
         }
     }
+    if ((ka.fault & 8u) && gi % 3u == 1u) f_bad = 2;   // test hook: every third workgroup gives the call up here, its neighbours have written or will
     if (__syncthreads_or(f_bad)) {
         if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;

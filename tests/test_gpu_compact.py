@@ -251,3 +251,40 @@ def test_workgroups_whose_entry_state_is_wrong_repair_themselves(ctx, warm):
         ctx.lib.kpeg_hip_debug_set(ctx._h, 2, -1)
         ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
         ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)
+
+
+def test_the_launches_behind_k_sync_write_finish_a_call_it_gives_up(ctx):
+    """Since its workgroups repair themselves k_sync_write gives a call up only when a stream does not re-synchronise inside a
+    workgroup or a wait expires -- nothing a test picture does.  Fault bit 3 (debug key 6, value 8) makes every third workgroup
+    give up behind its hand-over, when some of its neighbours have written their coefficients and others have not: the launches
+    enqueued behind the kernel must then decode the call (more than one launch of K1 with work), pixels the oracle's, and the
+    call after it, without the fault, is the one kernel's again."""
+    import libkpeg_amd as K
+    cases = [("synthetic 2048x1024", T.synth_jpeg(2048, 1024, seed=6, quality=75, sigma=6.0)),
+             ("synthetic 4096x2048", T.synth_jpeg(4096, 2048, seed=7, quality=75, sigma=6.0))]
+    try:
+        import PIL  # noqa: F401
+        sys.path.insert(0, T.ROOT)
+        import bench
+        cases.append(("lena tiled to 2048x1024, q75", bench.tiled_photo_jpeg("lena.jpg", 75, 2048, 1024)))
+    except ImportError:
+        pass
+    try:
+        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 2) == 0
+        for what, data in cases:
+            st, want = T.oracle_decode(data)
+            assert st == T.DECODE_DONE
+            rc, frame, scan = K.host_parse(data)
+            assert rc == K.DECODE_DONE
+            for fault, rounds_ok in ((8, lambda r: r >= 2), (0, lambda r: r == 1), (8, lambda r: r >= 2)):
+                assert ctx.lib.kpeg_hip_debug_set(ctx._h, 6, fault) == 0
+                ctx.set_profiling(True)
+                got = ctx.decode_scan(frame, scan)
+                rounds = int(ctx.timings()["sync_rounds"])
+                ctx.set_profiling(False)
+                bad = np.argwhere(got != want)
+                assert bad.size == 0, "%s fault %d: first mismatches (y,x,c) %s of %d" % (what, fault, bad[:8].tolist(), len(bad))
+                assert rounds_ok(rounds), (what, fault, rounds)
+    finally:
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 6, 0)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
