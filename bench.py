@@ -682,11 +682,11 @@ def main():
         if copy_gbs:
             roof["device_copy_GBs"] = round(copy_gbs, 1)   # measured ceiling: 256 MiB device-to-device copy, read + write bytes
         # HIP events between the launches: each span holds its kernel(s) and the gap to the next event, so their sum exceeds ms_per_step
-        # (the timed loop has no events).  Where k_sync_write did K1's pass 0 and K2 in one kernel, the launches behind it leave at once:
-        # the keys say so instead of naming kernels that did no work.
+        # (the timed loop has no events).  Where k_sync_write did K1's pass 0 and K2 in one kernel, its second (strict) launch leaves at once and
+        # no other entropy kernel is enqueued: the keys say so instead of naming kernels that did not run.
         one_k = (tm.get("sync_rounds") or 0) == 1 and (tm.get("huff_write_ms") or 1.0) < 0.015 and not args.idct_only
-        names = {"huff_sync_ms": "k_sync_write_ms", "huff_scan_ms": "idle_sync_launches_ms", "huff_write_ms": "idle_k_write_launch_ms", "dc_ms": "gap_before_K4_ms",
-                 "unstuff_ms": "gap_before_entropy_ms"} if one_k else {"dc_ms": "gap_before_K4_ms"}
+        names = {"huff_sync_ms": "k_sync_write_and_its_idle_second_launch_ms", "huff_scan_ms": "gap_behind_entropy_ms", "huff_write_ms": "gap_behind_entropy_2_ms",
+                 "dc_ms": "gap_before_K4_ms", "unstuff_ms": "gap_before_entropy_ms"} if one_k else {"dc_ms": "gap_before_K4_ms"}
         kernels_ms = {names.get(k, k): round(v, 5) for k, v in tm.items() if k.endswith("_ms")}
         kernels_ms["note"] = "event-to-event spans (kernel + launch gap); their sum exceeds ms_per_step, which is timed without events"
         out = {

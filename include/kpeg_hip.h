@@ -79,20 +79,21 @@ typedef struct kpeg_frame {
  * not run.  What the spans bracket depends on the path the call took:
  *   separate launches (restart segments, batches, dense streams, KPEG_FUSED=0): the names say it;
  *   one image on the compact stream (k_sync_write: K1's pass 0 and K2 in one kernel): huff_sync_ms is that kernel together
- *   with the verifying and the chained launch behind it, huff_write_ms the k_write launch -- all three leave at once unless
- *   the kernel gave the call up. */
+ *   with its second, strict launch, which leaves at once unless the first gave the call up; huff_scan_ms, huff_write_ms and
+ *   dc_ms are the gaps between event records (no kernel runs in them). */
 typedef struct kpeg_hip_timings {
     float unstuff_ms;      /* K0: FF00 removal / restart-segment scan (restart segments and batches only: one image
                               without restart markers is un-stuffed by K1 and K2 as they stage it)                       */
-    float huff_sync_ms;    /* K1: self-synchronising sub-sequence decode, all its launches; or k_sync_write + the two
-                              idle launches behind it (see above)                                                         */
+    float huff_sync_ms;    /* K1: self-synchronising sub-sequence decode, all its launches; or k_sync_write's two launches
+                              (see above)                                                                                 */
     float huff_scan_ms;    /*     (the scan of the totals runs inside K1's last launch: this span is a launch gap)       */
-    float huff_write_ms;   /* K2: coefficient-writing decode pass (k_write); idle behind k_sync_write                    */
+    float huff_write_ms;   /* K2: coefficient-writing decode pass (k_write); a gap behind k_sync_write                   */
     float dc_ms;           /*     (no DC kernel any more: the DC sums ride in K1's totals; a launch gap)                 */
     float idct_ms;         /* K4: dequantise + IDCT + level shift + colour + tiled RGB store                             */
     float total_ms;        /* sum of the spans, first event -> last event                                                */
     uint32_t sync_rounds;  /* launches of K1 that had work: 1 = pass 0 (or k_sync_write) settled every workgroup,
-                              2 = the verifying launch decoded again, 3 = the chained launch rippled                     */
+                              2 = the verifying launch (or k_sync_write's second launch) decoded again, 3 = the chained
+                              launch rippled                                                                              */
     uint32_t exact_pixels; /* K4: pixels that took the reference-order re-evaluation                                     */
 } kpeg_hip_timings;
 

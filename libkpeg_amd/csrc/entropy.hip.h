@@ -289,6 +289,7 @@ struct EntropyMeta {   // device-resident bookkeeping written by K0
     uint32_t k1_order;   // K1's chained pass: logical workgroup index = the order in which workgroups start (K0 clears it)
     uint32_t fused_fail; // == the call's number: k_sync_write could not finish the call (the three launches behind it do)
     uint32_t repaired;   // workgroups of k_sync_write that found their entry state wrong and put it right themselves (ever: tools read the difference)
+    uint32_t strict_order;   // k_sync_write's second launch: logical workgroup index = the order in which its workgroups start (the first launch clears it)
 };
 
 // Waits between workgroups never rest on the order in which the hardware dispatches blockIdx (HIP promises none):
@@ -1275,10 +1276,12 @@ struct SyncArgs {
     // k_sync_write (K1's pass 0 and K2 in one kernel): the call's number (never 0; 0 = not that path), and two words per
     // workgroup that take it: its presets are done / its totals and states are published
     uint32_t gen;
+    uint32_t gen2;      // k_sync_write's second launch: the number its own records carry (gen: the call's, which fused_fail must carry for it to run)
     unsigned long long* pub;   // [nwg_cap][PUB_WORDS] then [nwg_cap][PUB2_WORDS]: value | call number << 32, relaxed atomics both ways
 };
 constexpr uint64_t X_NONE = ~0ull;
 constexpr uint32_t PUB_WORDS = 9;   // blocks, dc0, dc1, dc2, records, exit state lo / hi, assumed entry state lo / hi
+constexpr uint32_t PUB3_WORDS = 7;  // k_sync_write's second (strict) launch: final exit state lo / hi, then blocks, dc0, dc1, dc2, records up to and including the workgroup; behind the second records
 constexpr uint32_t PUB2_WORDS = 5;  // a workgroup that repaired itself: blocks, dc0, dc1, dc2, records once more, at pub + nwg_cap PUB_WORDS
 
 // Appends v to list[] for every lane that wants to; call with the whole wavefront converged.
@@ -1505,7 +1508,9 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             return;
         }
     }
+#define K1_BODY_BEFORE_ROUNDS
 #include "k1_wg_body.inc.h"
+#undef K1_BODY_BEFORE_ROUNDS
     if (a.chained) {
         __syncthreads();
         finish_chained();
@@ -1622,8 +1627,10 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     const uint64_t tw1 = __builtin_amdgcn_s_memtime();
 #endif
 #define K2_S_START s_start
+#define K2_WG blockIdx.x
 #include "k2_scan.inc.h"
 #include "k2_core.inc.h"
+#undef K2_WG
 #undef K2_S_START
 }
 
@@ -1638,7 +1645,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
 // workgroup writes nothing and says so in meta->fused_fail: the verifying launch, the chained launch and k_write are
 // enqueued behind this kernel in any case and leave at once unless that word carries the call's number -- pass 0's results
 // are all in place for them.  Every wait is bounded (SpinGuard) and only ever for workgroups with a smaller index.
-template <int S>
+template <int S, bool STRICT>
 __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sync_write(SyncArgs ka, WriteArgs a)
 {
     KPEG_GEOMETRY(S);
@@ -1663,8 +1670,29 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     __shared__ uint64_t s_hx[2 * (SYNC_WG / 64) + 1];
     const bool stuffed = true;   // (the host takes this path for such calls only)
     const uint32_t nsub = ka.nsub_host, nseg = 1u, n_u = 0u;
-    const uint32_t i0 = blockIdx.x * OWN;
+    // The kernel is enqueued twice.  The second launch (STRICT) leaves at once unless the first gave the call up (a stream that does not
+    // re-synchronise inside a workgroup's sub-sequences, an expired wait): then it does the call again the slow, sure way -- every workgroup
+    // waits for the FINAL exit state and the totals up to its predecessor before it settles its own sub-sequences from the results the first
+    // launch left, one after the other along the stream (the bits and tables are staged before the wait: a link of that chain is a look
+    // and a publication, a microsecond, unless something has to be decoded again), then writes.  Its workgroups take their index from a
+    // ticket, so a predecessor is always running or done whatever the dispatch order.  (Rounds 1-3 had three launches here -- verifying,
+    // chained, k_write -- which cost the headline 6 us of doing nothing: profiles/r03_i.)
+    uint32_t gi_ = blockIdx.x;
+    if constexpr (STRICT) {
+        if (ka.meta->fused_fail != ka.gen) return;
+        if (threadIdx.x == 0) s_n[0] = atomicAdd(&ka.meta->strict_order, 1u);
+        __syncthreads();
+        gi_ = s_n[0];
+        __syncthreads();
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ka.meta->strict_order = 0u;
+    }
+    const uint32_t gi = gi_, ti = threadIdx.x;
+    const uint32_t i0 = gi * OWN;
     if (i0 >= nsub) return;
+    if constexpr (STRICT) {
+        if (ti == 0) atomicExch(&ka.bslot[gi], 0ull);   // (the exchange slot with the next workgroup: the first launch may have used it)
+    }
 #ifndef KPEG_FUSED_PRIO
 #define KPEG_FUSED_PRIO 2
 #endif
@@ -1678,16 +1706,78 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     int4 k1_cnt = make_int4(0, 0, 0, 0);
     uint32_t k1_nrec = 0, k1_wu = 0;
     bool k1_own = false;
-    {
+    uint64_t x_before = 0;   // the exit state of the sub-sequence before this workgroup's first
+    if constexpr (STRICT) {
+        const SyncArgs& a = ka;
+        const int p = 1;
+        const uint32_t g = gi, t = threadIdx.x;
+        uint64_t* const Xb_cur = a.Xb;
+        const uint64_t* const Xb_prev = a.Xb;   // (what a later pass compares and counts for the launch behind it: nothing here)
+        const bool mute = false;
+        uint64_t entry = 0;
+        auto strict_wait = [&]() {
+            if (t == 0) {
+                unsigned long long v[PUB3_WORDS];
+#pragma unroll
+                for (uint32_t q = 0; q < PUB3_WORDS; ++q) v[q] = 0;
+                if (g > 0) {
+                    const unsigned long long* pw = a.pub + (size_t)a.nwg_cap * (PUB_WORDS + PUB2_WORDS) + (size_t)(g - 1) * PUB3_WORDS;
+                    SpinGuard guard(K1_SPIN_TICKS);
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (uint32_t q = 0; q < PUB3_WORDS; ++q) {
+                            v[q] = __hip_atomic_load(pw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && (uint32_t)(v[q] >> 32) == a.gen2;
+                        }
+                        if (ok) break;
+                        if (guard.expired()) {   // (cannot happen: the predecessor by ticket is running or done; bounded like every wait)
+                            atomicOr(&a.status[1], KPEG_ERR_TIMEOUT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                s_hx[2 * (SYNC_WG / 64)] = (uint64_t)(uint32_t)v[0] | ((uint64_t)(uint32_t)v[1] << 32);
+                s_hsum[0] = make_int4((int)(uint32_t)v[2], (int)(uint32_t)v[3], (int)(uint32_t)v[4], (int)(uint32_t)v[5]);
+                s_hrec[0] = (uint32_t)v[6];
+            }
+            __syncthreads();
+            entry = s_hx[2 * (SYNC_WG / 64)];
+        };
+#define K1_BODY_BEFORE_ROUNDS strict_wait();
+#include "k1_wg_body.inc.h"
+#undef K1_BODY_BEFORE_ROUNDS
+        k1_exit = r.exit_state;
+        k1_cnt = r.cnt;
+        k1_nrec = r.nrec;
+        k1_wu = wu;
+        k1_own = have && t >= wu;
+        x_before = entry;
+        __syncthreads();
+        if (t == 0) {
+            // final: this workgroup's last exit state and the totals up to and including it
+            const int4 w = a.wsum[g];   // (this thread's own stores)
+            const uint32_t wr = a.wrec[g];
+            const int4 pre = s_hsum[0];
+            const uint64_t last = s_edge[1];
+            const uint32_t vals[PUB3_WORDS] = {(uint32_t)last, (uint32_t)(last >> 32), (uint32_t)(pre.x + w.x), (uint32_t)(pre.y + w.y), (uint32_t)(pre.z + w.z), (uint32_t)(pre.w + w.w), s_hrec[0] + wr};
+            unsigned long long* const p3 = a.pub + (size_t)a.nwg_cap * (PUB_WORDS + PUB2_WORDS) + (size_t)g * PUB3_WORDS;
+            for (uint32_t q = 0; q < PUB3_WORDS; ++q)
+                __hip_atomic_store(p3 + q, (unsigned long long)vals[q] | ((unsigned long long)a.gen2 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
         const SyncArgs& a = ka;
         const int p = 0;
-        const uint32_t g = blockIdx.x, t = threadIdx.x;
+        const uint32_t g = gi, t = threadIdx.x;
         uint64_t* const Xb_cur = a.Xb;
         const uint64_t* const Xb_prev = a.Xb + a.nwg_cap;
         const bool mute = false;
         const uint64_t entry = 0;
         (void)Xb_prev;
+#define K1_BODY_BEFORE_ROUNDS
 #include "k1_wg_body.inc.h"
+#undef K1_BODY_BEFORE_ROUNDS
         k1_exit = r.exit_state;
         k1_cnt = r.cnt;
         k1_nrec = r.nrec;
@@ -1696,12 +1786,11 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         k1_as = s_edge[0];   // (what this workgroup's first own item decoded from: written before the body's last barrier)
         // (the body's thread 0 has published the totals, the last exit state and the assumption: a.gen != 0)
     }
-    const uint32_t gi = blockIdx.x, ti = threadIdx.x;
     const uint64_t k1_last = s_edge[1];   // this workgroup's last exit state, as published (written before the body's last barrier)
     // The exit state this workgroup's first own item has to have started from: the last one of the workgroup before.  Asked for now,
     // looked at behind the hand-over below (thread 0).
     unsigned long long xq0 = 0, xq1 = 0;
-    if (ti == 0 && gi > 0) {
+    if (!STRICT && ti == 0 && gi > 0) {
         xq0 = __hip_atomic_load(ka.pub + (size_t)(gi - 1) * PUB_WORDS + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         xq1 = __hip_atomic_load(ka.pub + (size_t)(gi - 1) * PUB_WORDS + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1739,6 +1828,10 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
     hand_over();
     __builtin_amdgcn_s_setprio(0);
     int f_bad = 0;
+#if KPEG_SYNC_STATS
+    uint64_t tw1 = 0;
+#endif
+    if constexpr (!STRICT) {
     // ---- this workgroup's own assumption ----
     // Its first own item decoded from the state its lead-in items arrived at; the state it had to start from is the last exit state of the
     // workgroup before (final as published: a workgroup's last item has re-synchronised hundreds of items after its first, whatever that
@@ -1763,7 +1856,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const uint64_t x_before = gi > 0 ? s_hx[2 * (SYNC_WG / 64)] : 0ull;   // the exit state of the sub-sequence before this workgroup's first
+    x_before = gi > 0 ? s_hx[2 * (SYNC_WG / 64)] : 0ull;
     if (gi > 0 && k1_as != X_NONE && k1_as != x_before) {   // (the same for every thread)
         __builtin_amdgcn_s_setprio(KPEG_FUSED_PRIO);
         {
@@ -1774,7 +1867,9 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
             const uint64_t* const Xb_prev = a.Xb;   // (what a later pass compares and counts for the launch behind it: nothing here)
             const bool mute = false;
             const uint64_t entry = x_before;
+#define K1_BODY_BEFORE_ROUNDS
 #include "k1_wg_body.inc.h"
+#undef K1_BODY_BEFORE_ROUNDS
             k1_exit = r.exit_state;
             k1_cnt = r.cnt;
             k1_nrec = r.nrec;
@@ -1880,7 +1975,7 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         }
     }
 #if KPEG_SYNC_STATS
-    const uint64_t tw1 = __builtin_amdgcn_s_memtime();   // this wavefront has every record it takes
+    tw1 = __builtin_amdgcn_s_memtime();   // this wavefront has every record it takes
 #endif
     {
         const uint32_t lane = ti & 63, wave = ti >> 6;
@@ -1896,12 +1991,19 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
         if (ti == 0) __hip_atomic_store(&ka.meta->fused_fail, ka.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (gi == 0 && ti == 0) ka.status[2] = 1u;   // launches of K1 that had work (the launches behind this kernel say more if they run)
+    }
     int4 wsum_g = make_int4(0, 0, 0, 0);
     uint32_t wrec_g = 0;
-    for (uint32_t q = 0; q < SYNC_WG / 64; ++q) {
-        wsum_g = add4(wsum_g, s_hsum[q]);
-        wrec_g += s_hrec[q];
+    if constexpr (STRICT) {
+        if (gi == 0 && ti == 0) ka.status[2] = 2u;   // (launches of K1 that had work)
+        wsum_g = s_hsum[0];
+        wrec_g = s_hrec[0];
+    } else {
+        if (gi == 0 && ti == 0) ka.status[2] = 1u;   // launches of K1 that had work (the second launch says more if it runs)
+        for (uint32_t q = 0; q < SYNC_WG / 64; ++q) {
+            wsum_g = add4(wsum_g, s_hsum[q]);
+            wrec_g += s_hrec[q];
+        }
     }
     if (valid && ti == 0 && i > 0) x_prev = x_before;
     SubGeom g0;
@@ -1915,7 +2017,9 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
 #endif
     uint32_t* const k2_start = s_start + k1_wu;
 #define K2_S_START k2_start
+#define K2_WG gi
 #include "k2_core.inc.h"
+#undef K2_WG
 #undef K2_S_START
 }
 
@@ -2088,7 +2192,7 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     sa.nparts = stuffed ? 0u : nparts;   // (K0's look-back words: untouched without K0)
     // One kernel for K1's pass 0 and K2 (k_sync_write) where it applies; the launches below follow it in any case and leave
     // at once unless it gave up.
-    bool fuse = false;
+    bool fuse = false, fuse_strict = false;
     // (both sub-sequence sizes since round 3: with the long ones an 8K photograph at 3-4 bit/px saves the verifying launch's second
     // decode and K2's prologue, 1-4 % of the call: profiles/r03_e)
 #ifdef KPEG_NO_FUSE_DENSE
@@ -2099,21 +2203,28 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
         fuse = stuffed && L.d_tile_start && !L.gray && !L.sub420 && L.sync_passes == 0 && L.fused_slots && nwg_cap <= FUSED_MAX_WG;
         if (fuse) {
             const size_t cap_before = S->flags_cap;
-            if ((rc = ent_grow(&S->d_flags, &S->flags_cap, (size_t)nwg_cap * (PUB_WORDS + PUB2_WORDS) * sizeof(unsigned long long), L.stream, err))) return rc;
+            if ((rc = ent_grow(&S->d_flags, &S->flags_cap, (size_t)nwg_cap * (PUB_WORDS + PUB2_WORDS + PUB3_WORDS) * sizeof(unsigned long long), L.stream, err))) return rc;
             bool wipe = S->flags_cap != cap_before;   // (a new allocation -- even at the old address -- holds anything)
-            if (++S->gen == 0) {
-                ++S->gen;   // 0 is "not that path"
-                wipe = true;   // the call numbers start over: nothing an earlier call published may pass for this one's
+            if (S->gen >= 0xFFFFFFFDu) {
+                S->gen = 0;   // the call numbers start over: nothing an earlier call published may pass for this one's
+                wipe = true;
             }
+            S->gen += 2;   // (never 0: 0 is "not that path"; the second launch's records carry the number after the call's)
             if (wipe) ENT_HIP(hipMemsetAsync(S->d_flags, 0, S->flags_cap, L.stream));
             sa.gen = wa.gen = S->gen;
+            sa.gen2 = S->gen + 1;
             sa.pub = (unsigned long long*)S->d_flags;
             sa.pass = 0;
             sa.chained = 0;
-            hipLaunchKernelGGL((k_sync_write<SB>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa, wa);
+            hipLaunchKernelGGL((k_sync_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa, wa);
+#ifndef KPEG_FUSED_THREE_LAUNCHES
+            // ... and once more, the sure way, if that launch gave the call up (it leaves at once if not)
+            fuse_strict = true;
+            hipLaunchKernelGGL((k_sync_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa, wa);
+#endif
         }
     }
-    for (int t = fuse ? 1 : 0; t < npass; ++t) {
+    for (int t = fuse ? 1 : 0; t < npass && !fuse_strict; ++t) {
         sa.pass = t;
         sa.chained = t == npass - 1 ? 1 : 0;
         if (L.sub420) hipLaunchKernelGGL((k_sync_pass<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, sa);
@@ -2122,7 +2233,9 @@ static int entropy_decode_launch_s(EntropyScratch* S, const EntropyTables& tabs,
     }
     mark(2);
     mark(3);
-    if (L.sub420) hipLaunchKernelGGL((k_write<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
+    if (fuse_strict) {
+        // (k_sync_write's two launches have written the coefficients)
+    } else if (L.sub420) hipLaunchKernelGGL((k_write<SB, false, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else if (L.d_tile_start) hipLaunchKernelGGL((k_write<SB, true>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     else hipLaunchKernelGGL((k_write<SB, false>), dim3(nwg_cap), dim3(SYNC_WG), 0, L.stream, wa);
     mark(4);

@@ -1,7 +1,7 @@
 // libkpeg_amd/csrc/k1_wg_body.inc.h -- the work of ONE workgroup of K1 on its sub-sequences: stage, decode, settle inside
 // the workgroup, count, store.  Not a header: the text of a function body, included by k_sync_pass and by k_sync_write (K1's
 // pass 0 and K2 in one kernel).  Expects in scope: a (SyncArgs), S, COUNT, S420, p, g, t, i0, entry, stuffed, nsub, nseg,
-// n_u, Xb_cur, Xb_prev, mute and the __shared__ arrays T, s_lutx, s_wexit, s_wdone, s_edge, s_start, s_n, s_red, s_redn,
+// n_u, Xb_cur, Xb_prev, mute, the macro K1_BODY_BEFORE_ROUNDS (code or nothing) and the __shared__ arrays T, s_lutx, s_wexit, s_wdone, s_edge, s_start, s_n, s_red, s_redn,
 // s_bits, STAGE_CAP.
 
 #if KPEG_SYNC_STATS
@@ -163,6 +163,7 @@
         }
     }
 #endif
+    K1_BODY_BEFORE_ROUNDS   // (k_sync_write's second, strict launch waits here -- its bits and tables staged -- for the entry state it is to start from)
     __syncthreads();
 #if KPEG_SYNC_STATS
     const uint64_t tmc = __builtin_amdgcn_s_memtime();

@@ -4,7 +4,7 @@
 // included by k_write (after its loads and staging) and by k_sync_write (after K1's work on the same workgroup and the wait
 // for its predecessors).  Expects in scope: a (WriteArgs), S, COMPACT, S420, T, s_pre, s_prer, s_wred, s_wredr, s_bits,
 // K2_S_START (first bit of the chunk of lane threadIdx.x), stuffed, nsub, nseg, n_u, i0, i, valid, nrec_i, x_prev, wsum_g,
-// wrec_g, g0, w0 (and, stats builds, tw0, tw1, st_steps).
+// wrec_g, g0, w0, K2_WG (the workgroup's index) (and, stats builds, tw0, tw1, st_steps).
 
     // ... + the workgroup's offset, counted from the start of the restart segment.  A segment that began in
     // this workgroup re-bases on a neighbour's scan value; the one open at the workgroup's first
@@ -330,10 +330,10 @@
         }
         if (side == 0 && found) settle(hgb, A, n, crn, hchroma);
         // the part of the block on this side of a workgroup boundary: swap it for the other side's
-        const bool to_prev = side == 0 && !found && !broken && blockIdx.x > 0;   // began before this workgroup
+        const bool to_prev = side == 0 && !found && !broken && K2_WG > 0;   // began before this workgroup
         const bool to_next = side == 1 && found;                                  // goes on after this workgroup
         if (to_prev || to_next) {
-            const unsigned long long other = atomicExch(&a.bslot[to_prev ? blockIdx.x - 1 : blockIdx.x], pack(A, n, crn));
+            const unsigned long long other = atomicExch(&a.bslot[to_prev ? K2_WG - 1 : K2_WG], pack(A, n, crn));
             if (other) {
                 // the sum runs in stream order on both sides: earlier part + later part
                 const float Ao = __uint_as_float((uint32_t)other);
@@ -352,7 +352,7 @@
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
             sm += (uint32_t)__shfl_xor((int)sm, o);
         }
-        const uint32_t wid = blockIdx.x * (SYNC_WG / 64) + (threadIdx.x >> 6);
+        const uint32_t wid = K2_WG * (SYNC_WG / 64) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0 && wid < 8192) {
             unsigned long long* o = &g_ent_stamp[1][wid * 16];
             o[0] = tw0;

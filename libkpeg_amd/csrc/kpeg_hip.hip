@@ -196,7 +196,7 @@ extern "C" int kpeg_hip_create(kpeg_hip_ctx** out, int device)
         if (const char* s = std::getenv("KPEG_FORCE_K0")) ctx->force_k0 = std::atoi(s) ? 1u : 0u;
         {
             int nf = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, kpeg_dev::k_sync_write<kpeg_dev::SUBSEQ_SPARSE>, kpeg_dev::SYNC_WG, 0) == hipSuccess && nf > 0)
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, kpeg_dev::k_sync_write<kpeg_dev::SUBSEQ_SPARSE, false>, kpeg_dev::SYNC_WG, 0) == hipSuccess && nf > 0)
                 ctx->fused_slots_dev = (uint32_t)nf * (uint32_t)ctx->num_cus;
             ctx->fused_slots = ctx->fused_slots_dev;
             if (const char* s = std::getenv("KPEG_FUSED")) ctx->fused_slots = std::atoi(s) ? ctx->fused_slots_dev : 0u;   // experiments: as debug key 9

@@ -253,12 +253,14 @@ def test_workgroups_whose_entry_state_is_wrong_repair_themselves(ctx, warm):
         ctx.lib.kpeg_hip_debug_set(ctx._h, 9, 1)
 
 
-def test_the_launches_behind_k_sync_write_finish_a_call_it_gives_up(ctx):
+def test_the_second_launch_of_k_sync_write_finishes_a_call_the_first_gives_up(ctx):
     """Since its workgroups repair themselves k_sync_write gives a call up only when a stream does not re-synchronise inside a
     workgroup or a wait expires -- nothing a test picture does.  Fault bit 3 (debug key 6, value 8) makes every third workgroup
-    give up behind its hand-over, when some of its neighbours have written their coefficients and others have not: the launches
-    enqueued behind the kernel must then decode the call (more than one launch of K1 with work), pixels the oracle's, and the
-    call after it, without the fault, is the one kernel's again."""
+    give up behind its hand-over, when some of its neighbours have written their coefficients and others have not: the kernel's
+    second, strict launch must then decode the call (two launches of K1 with work), pixels the oracle's, and the call after it,
+    without the fault, is the first launch's alone again.  With the short and the long sub-sequences, and with K1's lead-in cut
+    to nothing, so that the results the first launch leaves are wrong at every workgroup's edge and the strict chain has to
+    decode again wherever it goes.  A truncated stream must fail the same way through either."""
     import libkpeg_amd as K
     cases = [("synthetic 2048x1024", T.synth_jpeg(2048, 1024, seed=6, quality=75, sigma=6.0)),
              ("synthetic 4096x2048", T.synth_jpeg(4096, 2048, seed=7, quality=75, sigma=6.0))]
@@ -276,15 +278,34 @@ def test_the_launches_behind_k_sync_write_finish_a_call_it_gives_up(ctx):
             assert st == T.DECODE_DONE
             rc, frame, scan = K.host_parse(data)
             assert rc == K.DECODE_DONE
-            for fault, rounds_ok in ((8, lambda r: r >= 2), (0, lambda r: r == 1), (8, lambda r: r >= 2)):
+            for subseq in (0, 384):
+                for warm in (-1, 0):
+                    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, subseq) == 0
+                    assert ctx.lib.kpeg_hip_debug_set(ctx._h, 2, warm) == 0
+                    for fault, rounds_ok in ((8, lambda r: r == 2), (0, lambda r: r == 1), (8, lambda r: r == 2)):
+                        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 6, fault) == 0
+                        ctx.set_profiling(True)
+                        got = ctx.decode_scan(frame, scan)
+                        rounds = int(ctx.timings()["sync_rounds"])
+                        ctx.set_profiling(False)
+                        bad = np.argwhere(got != want)
+                        assert bad.size == 0, "%s subseq %d warm %d fault %d: first mismatches (y,x,c) %s of %d" % (what, subseq, warm, fault, bad[:8].tolist(), len(bad))
+                        assert rounds_ok(rounds), (what, subseq, warm, fault, rounds)
+            # a truncated stream: the same answer with and without the fault
+            ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 0)
+            ctx.lib.kpeg_hip_debug_set(ctx._h, 2, -1)
+            cut = scan[:len(scan) * 2 // 3]
+            codes = []
+            for fault in (0, 8):
                 assert ctx.lib.kpeg_hip_debug_set(ctx._h, 6, fault) == 0
-                ctx.set_profiling(True)
-                got = ctx.decode_scan(frame, scan)
-                rounds = int(ctx.timings()["sync_rounds"])
-                ctx.set_profiling(False)
-                bad = np.argwhere(got != want)
-                assert bad.size == 0, "%s fault %d: first mismatches (y,x,c) %s of %d" % (what, fault, bad[:8].tolist(), len(bad))
-                assert rounds_ok(rounds), (what, fault, rounds)
+                try:
+                    ctx.decode_scan(frame, cut)
+                    codes.append(0)
+                except K.KpegError as e:
+                    codes.append(e.code)
+            assert codes[0] == codes[1] == K.E_STREAM, (what, codes)
     finally:
         ctx.lib.kpeg_hip_debug_set(ctx._h, 6, 0)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 0)
+        ctx.lib.kpeg_hip_debug_set(ctx._h, 2, -1)
         ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
