@@ -32,10 +32,12 @@
 //                 the second still moved something -- no stream is given up -- and in any case runs the
 //       scan      exclusive prefix sum of (blocks, dc[3], records) over the workgroups: with K2's local
 //                 scan, absolute block index, DC predictors and record ordinal at every sub-sequence entry.
-//   K1 + K2 in one kernel (k_sync_write) where it applies -- one image without restart markers on the compact stream, a
-//                 grid that is resident at once: a workgroup does K1's pass 0, publishes, adds up its predecessors' totals,
-//                 checks every assumption up to its own and writes (K2's core) from the bits and tables it has in LDS; the
-//                 launches above and K2 follow it and leave at once unless a check failed or a wait expired.
+//   K1 + K2 in one kernel (k_sync_write) where it applies -- one image without restart markers on the compact stream, up
+//                 to 4096 workgroups, either sub-sequence size: a workgroup does K1's pass 0, publishes, checks the entry state
+//                 it assumed against its predecessor's exit state (and does K1's work again from the right one if it was
+//                 wrong, publishing its totals a second time), adds up its predecessors' totals and writes (K2's core) from
+//                 the bits and tables it has in LDS.  The kernel is enqueued twice: its second, strict launch leaves at once
+//                 unless the first gave the call up (a stream that never re-synchronises inside a workgroup, an expired wait).
 //   K2  write     one lane per sub-sequence decodes its own symbols again from its true entry
 //                 state and writes what K4 reads -- the non-zero coefficients scattered into the cleared dense
 //                 buffer (natural order, absolute DC, quirk Q1 applied), or, compact stream, a 4-byte record per
@@ -1635,16 +1637,16 @@ __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
 }
 
 // K1's pass 0 and K2 in ONE kernel, for the case the headline is: one image without restart markers (no K0), the compact
-// coefficient stream, three components, sparse sub-sequences, and a grid that is resident all at once.  A workgroup does
-// K1's work on its sub-sequences (k1_wg_body.inc.h, as pass 0), publishes its totals, its last exit state and the entry
-// state it assumed, then waits until every workgroup before it has published, adds their totals up -- that is the scan --
-// and checks every assumption up to its own against the exit state it has to match.  If they all hold it writes its
-// coefficients straight away (k2_core.inc.h), from the tables and the bits it has in LDS already: no second prologue, no
-// verifying, chained or scan launch, and the workgroups in front of the image's slowest chain of re-decodes write while
-// that chain is still being walked.  If one does not hold (photographs: somewhere, always), or a wait expires, the
-// workgroup writes nothing and says so in meta->fused_fail: the verifying launch, the chained launch and k_write are
-// enqueued behind this kernel in any case and leave at once unless that word carries the call's number -- pass 0's results
-// are all in place for them.  Every wait is bounded (SpinGuard) and only ever for workgroups with a smaller index.
+// coefficient stream, three components, at most FUSED_MAX_WG workgroups.  A workgroup does K1's work on its sub-sequences
+// (k1_wg_body.inc.h, as pass 0), publishes its totals, its last exit state and the entry state it assumed, checks that
+// assumption against the exit state of the workgroup before it (and repairs itself if it was wrong: K1's work once more as a
+// later pass does it, totals published a second time), then waits until every workgroup before it has published, adds their
+// totals up -- that is the scan -- and writes its coefficients straight away (k2_core.inc.h), from the tables and the bits it
+// has in LDS already: no second prologue, no verifying, chained or scan launch, and the workgroups in front of the image's
+// slowest chain of re-decodes write while that chain is still being walked.  If a repair moves the workgroup's exit state or
+// a wait expires, the workgroup writes nothing and says so in meta->fused_fail: the kernel's second launch (STRICT, see
+// below) then does the call again the sure way.  Every wait is bounded (SpinGuard) and only ever for workgroups with a
+// smaller index.
 template <int S, bool STRICT>
 __global__ __launch_bounds__(SYNC_WG) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_sync_write(SyncArgs ka, WriteArgs a)
 {
