@@ -42,6 +42,7 @@ def main():
                 frame, scan = T.make_frame(p, ri), p.scan
                 ctx.lib.kpeg_hip_debug_set(ctx._h, 7, int(rng.choice([0, 1, 2])))
                 ctx.lib.kpeg_hip_debug_set(ctx._h, 2, int(rng.choice([-1, -1, 0, 1, 3])))   # K1's lead-in: cut short, k_sync_write's workgroups repair themselves
+                ctx.lib.kpeg_hip_debug_set(ctx._h, 6, int(rng.choice([0, 0, 0, 8])))         # every third workgroup of k_sync_write gives up: its second launch decodes the call
             else:
                 w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
                 if kind == "gray":      # the grayscale oracle wants whole blocks
@@ -85,6 +86,7 @@ def main():
         finally:
             ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
             ctx.lib.kpeg_hip_debug_set(ctx._h, 2, -1)
+            ctx.lib.kpeg_hip_debug_set(ctx._h, 6, 0)
         n += 1
         kinds[kind] = kinds.get(kind, 0) + 1
         if not np.array_equal(got, want):
