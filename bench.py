@@ -660,7 +660,13 @@ def main():
         pixels_per_step = W * H * world
         ms_per_step = elapsed / args.steps * 1e3
         value = pixels_per_step / (ms_per_step * 1e-3) / 1e6
-        idct_ms = tm.get("idct_ms", 0.0)
+        # K4's duration: the span between the HIP events in front of and behind its launch, less what such a span holds when no kernel is
+        # launched in it -- the span in front of K4's (EV_WRITE -> EV_DC: there is no DC kernel any more) is exactly that, an event record
+        # and the gap to the next one, measured in the same pass (4.6-5.5 us).  rocprofv3's average for the kernel on the same command
+        # (profiles/r03_*_kernel_stats.csv) is what this has to agree with, and does within 2 %; the raw span read 8 % high.
+        idct_span_ms = tm.get("idct_ms", 0.0)
+        event_overhead_ms = tm.get("dc_ms", 0.0) if not args.idct_only else 0.0
+        idct_ms = idct_span_ms - event_overhead_ms if idct_span_ms > 2 * event_overhead_ms else idct_span_ms
         alg_bytes = 9.0 * W * H  # per launch: this rank's stripe
         traffic = traffic_source = None
         tf = os.path.join(ROOT, "profiles", "k4_traffic.json")
@@ -673,6 +679,7 @@ def main():
         roof = {"bound": "hbm", "achieved": round(alg_bytes / (idct_ms * 1e-3) / 1e9, 2) if idct_ms > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / (idct_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if idct_ms > 0 else None,
                 "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_idct_colour_fast", "kernel_ms": round(idct_ms, 5),
+                "kernel_ms_how": "HIP-event span around the launch (%.5f ms) less the span an event record alone takes (%.5f ms, the empty span in front of it)" % (idct_span_ms, event_overhead_ms),
                 "algorithmic_bytes": int(alg_bytes)}
         if traffic and traffic < alg_bytes:
             # the compact coefficient stream (the library's choice above 64 MiB of dense coefficients): K4 reads a tenth of the
@@ -722,7 +729,7 @@ def main():
                 "K1_sync": None if one_kernel else gbs(S, tm.get("huff_sync_ms")),
                 "K2_write": None if one_kernel else gbs(S + 6 * px, tm.get("huff_write_ms")),
                 "K1_K2_one_kernel": gbs(2 * S + 6 * px, (tm.get("huff_sync_ms") or 0) + (tm.get("huff_write_ms") or 0)) if one_kernel else None,
-                "K4_idct_colour": gbs(9 * px, tm.get("idct_ms")),
+                "K4_idct_colour": gbs(9 * px, idct_ms),
                 "end_to_end_fused_minimum": gbs((S + 3 * px) * world, ms_per_step)}
         if two_streams:
             out["two_streams"] = two_streams
