@@ -696,11 +696,10 @@ __device__ KPEG_FX_MANY_ATTR void fx_noncorner_many(lds_u32* entry, lds_cu32* im
                                                             __attribute__((address_space(3))) uint8_t* trow)
 {
     const uint32_t lane = (uint32_t)__lane_id();
-    const uint32_t g = lane >> 3, x = lane & 7u;   // MCU of the tile, pixel row
     const float c0 = 0x1.6a09e6p-1f;
-    lds_cf64* const cx = s_cos + x * 8;
-    // MCU::computeIDCT's sum for sample (x, y) of block c of the lane's MCU, in its order (MCU.cpp:184-198)
-    auto sum64 = [&](uint32_t c, uint32_t y) -> int {
+    // MCU::computeIDCT's sum for sample (x, y) of block c of MCU g of the tile, in its order (MCU.cpp:184-198)
+    auto sum64 = [&](uint32_t g, uint32_t x, uint32_t c, uint32_t y) -> int {
+        lds_cf64* const cx = s_cos + x * 8;
         lds_cf64* const cy = s_cos + y * 8;
         const __attribute__((address_space(3))) uint4v* const rows = reinterpret_cast<const __attribute__((address_space(3))) uint4v*>(img + (g * 3u + c) * 32u);
         lds_cu32* const qi = s_qi + (c ? 64 : 0);
@@ -727,30 +726,61 @@ __device__ KPEG_FX_MANY_ATTR void fx_noncorner_many(lds_u32* entry, lds_cu32* im
     };
     if (__ballot(inf != 0)) {   // wave-uniform; hostile or broken streams
         if (inf) {
+            const uint32_t g = lane >> 3, x = lane & 7u;   // MCU of the tile, pixel row
 #pragma unroll 1
             for (uint32_t y = 0; y < 8; ++y) {
                 int S[3];
 #pragma unroll 1
-                for (uint32_t c = 0; c < 3; ++c) S[c] = sum64(c, y);
+                for (uint32_t c = 0; c < 3; ++c) S[c] = sum64(g, x, c, y);
                 const uint32_t px = colour_exact(S[0], S[1], S[2]);
                 trow[y * 3] = (uint8_t)px, trow[y * 3 + 1] = (uint8_t)(px >> 8), trow[y * 3 + 2] = (uint8_t)(px >> 16);
             }
             entry[12] = 0xFFFFFFFFu;
             nc = 0;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    lds_u16* const eh = reinterpret_cast<lds_u16*>(entry);
-    uint32_t vouch = 0, mine = nc;
-    while (__ballot(mine != 0)) {   // wave-uniform
-        if (mine) {
-            const uint32_t b = 31u - (uint32_t)__builtin_clz(mine);
-            mine &= ~(1u << b);
+    // The samples are dealt to the lanes one by one, whatever rows they sit in: a cluster of ties puts up to 24 samples in ONE pixel
+    // row, and with a lane per row (round 3's first build) that lane's sums ran one after the other while 63 lanes looked on -- up to
+    // 14.5 us on one tile, and the wavefronts that met such tiles last were the kernel's tail (profiles/r03_k_*).  Sample number i of
+    // the tile (rows in lane order, a row's samples from its highest bit down) goes to lane i mod 64: the row it belongs to is found by
+    // a binary search over the rows' running counts (ds_bpermute: no memory), its value goes to that row's entry.
+    const uint32_t cnt = (uint32_t)__popc(nc), incl = wave_scan_incl(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t entry_addr = (uint32_t)(uintptr_t)entry;
+    for (uint32_t base = 0; base < total; base += 64) {   // wave-uniform
+        const uint32_t i = base + lane;
+        const bool act = i < total;
+        uint32_t owner = 0;   // rows whose running count is <= i
+#pragma unroll
+        for (uint32_t s = 32; s; s >>= 1) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((owner + s - 1) << 2), (int)incl);
+            owner += v <= i ? s : 0u;
+        }
+        owner = act ? owner : 63u;
+        uint32_t kth = i - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)(incl - cnt));   // the row's kth sample, from the highest bit down
+        uint32_t bits = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)nc);
+        const uint32_t eaddr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)entry_addr);
+        kth = act ? kth : 0u;
+        while (__ballot(kth != 0)) {   // wave-uniform: at most 23 rounds of three instructions
+            if (kth) {
+                bits &= ~(1u << (31u - (uint32_t)__builtin_clz(bits)));
+                --kth;
+            }
+        }
+        if (act && bits) {
+            const uint32_t b = 31u - (uint32_t)__builtin_clz(bits);
             const uint32_t c = b >> 3, y = 7u - (b & 7u);
-            eh[c * 8 + y] = __builtin_bit_cast(uint16_t, (_Float16)(float)(sum64(c, y) - 128));
-            vouch |= 1u << b;
+            const int S = sum64(owner >> 3, owner & 7u, c, y);
+            lds_u32* const eo = (lds_u32*)(uintptr_t)eaddr;
+            reinterpret_cast<lds_u16*>(eo)[c * 8 + y] = __builtin_bit_cast(uint16_t, (_Float16)(float)(S - 128));
+            // the entry vouches for the sample and no longer for the pixel's G term (fx_vouch, one bit at a time: several lanes may
+            // hold samples of one row)
+            __hip_atomic_fetch_or(eo + 12, 1u << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_and(eo + 12, ~(1u << (24u + (b & 7u))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    fx_vouch(entry, vouch);
 }
 
 // q: the wavefront's queue, nrows entries; s_qi: [2][64] quantisers, natural order.  Reads LDS only (an entry carries all it takes);
