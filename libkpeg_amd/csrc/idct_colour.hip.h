@@ -1195,7 +1195,9 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         else block_fast<4>(d2, lc, &s_m[1][u * 8], 1, v[2]);
 #endif
         // |fast - rint(fast)| + nthr >= 0  <=>  within the block's bound of a rounding boundary
+#if !KPEG_K4_MASK_MARKS
         const float nthr0 = fabsf(e0) - 0.5f, nthr1 = fabsf(e1) - 0.5f, nthr2 = fabsf(e2) - 0.5f;
+#endif
 
         // Level shift + colour for the 8 pixels of this lane's row.  Per pixel the sign of one word says whether the
         // reference-order evaluation is needed (sign clear): a fast value within its block's bound of a rounding boundary,
@@ -1203,7 +1205,26 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         // ties are structural: equal and opposite (0,1)/(1,0) terms cancel on a block's diagonal and leave DC/8 = n + 0.5
         // exactly); their signs are shifted into `ub`, one bit per pixel column.
         uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
+        // KPEG_K4_MASK_MARKS=1 (an experiment, measured and not the default): the pixel loop as planned below is 23 instead of 30 issue
+        // cycles of marking per pixel, but its ~24 scalar registers more push the kernel from 6 to 52 scalar spills (v_writelane /
+        // v_readlane around every tile): K4 63.2 -> 70.6 us (profiles/r03_k_k4_mask_marks_ab.txt).  It needs the kernel's scalar
+        // live set cut first (its arguments re-read per tile instead of kept).
+#ifndef KPEG_K4_MASK_MARKS
+#define KPEG_K4_MASK_MARKS 0
+#endif
+#if KPEG_K4_MASK_MARKS
+        // The marks as lane masks in scalar registers: every key is ONE vector compare (|v - rint v| against the block's threshold,
+        // written straight to a scalar register pair) in place of an add and a v_alignbit; the scalar unit ORs a pixel column's four
+        // masks, and one v_addc shifts the column's bit into the lane's byte (carry-in = the mask).  Which COMPONENT a mark is for is
+        // kept per pixel row only (four more masks): fx_flush evaluates a marked pixel's component in the reference's order when the
+        // row has a mark of that component at all (rows have 1.03 marked pixels on average; evaluating more than needed is always right).
+        const float thr0 = 0.5f - fabsf(e0), thr1 = 0.5f - fabsf(e1), thr2 = 0.5f - fabsf(e2);   // (== -nthr: the same decisions as the sign of |d| + nthr)
+        unsigned long long rowY = 0, rowB = 0, rowR = 0, rowG = 0;   // lanes whose pixel row has a mark of the component / of the G term
+        uint32_t ubM = 0;                                            // bit 7 - i = pixel column i is MARKED
+        const unsigned long long wide_mask = __ballot(wide);
+#else
         uint32_t ubY = 0, ubB = 0, ubR = 0, ubG = 0;   // per component and for the G term: bit 7 - i = pixel column i is safe
+#endif
         uint32_t hp[3][4];                              // the rounded samples as f16 pairs
         float py = 0.0f, pb = 0.0f, pr = 0.0f;          // the even column's, until its odd neighbour's are there
         // The loop exists twice: with the in-lane double colour conversion of `wide` MCUs and (nearly always) without.
@@ -1212,8 +1233,10 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
             for (int i = 0; i < 8; ++i) {
                 const float vy = v[0][i], vb = v[1][i], vr = v[2][i];
                 const float ry = __builtin_rintf(vy), rb = __builtin_rintf(vb), rr = __builtin_rintf(vr);
+#if !KPEG_K4_MASK_MARKS
                 // >= 0: the fast value is within its block's bound of a rounding boundary
                 const float fy = fabsf(vy - ry) + nthr0, fb = fabsf(vb - rb) + nthr1, fr = fabsf(vr - rr) + nthr2;
+#endif
                 // colour from the three rounded samples (minus the level shift); dt = how far the G term's t is from
                 // an integer, as seen by the f32 arithmetic
                 // v_cvt_pk_u8_f32 rounds to nearest-even and saturates.  All three channels are handed to it 0.499 below
@@ -1232,9 +1255,16 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
                 // |t| * 2^17 >= 1 there).  Both conditions and the three sample keys are combined as sign bits with
                 // and/or (1.7-cycle instructions; max/max3/rndne issue at 2.7): the sign of `safe` is set iff nothing
                 // about this pixel is unsafe.
+#if KPEG_K4_MASK_MARKS
+                // (not-less-than: a NaN marks)
+                const unsigned long long mY = __ballot(!(fabsf(vy - ry) < thr0)), mB = __ballot(!(fabsf(vb - rb) < thr1)), mR = __ballot(!(fabsf(vr - rr) < thr2));
+                unsigned long long mG = __ballot(!(fabsf((tc - t) - 0.5f) < (0.5f - KPEG_G_DELTA))) & __ballot(!(fabsf(t) < 4.0e-6f));   // within DELTA of an integer, and t != 0
+                uint32_t kg = 0;
+#else
                 const float ka = fabsf((tc - t) - 0.5f) - (0.5f - KPEG_G_DELTA);                // >= 0: within DELTA of an integer
                 const float kb = __builtin_fmaf(fabsf(t), 131072.0f, KPEG_G_DELTA - 1.0f);      // >= 0: t != 0
                 uint32_t kg = __float_as_uint(ka) | __float_as_uint(kb);                         // sign clear: G is unsafe
+#endif
                 if (decltype(with_wide)::value) {
                     if (wide) {
                         // out of the f32 colour arithmetic's range: the reference's own double arithmetic on the rounded samples
@@ -1249,13 +1279,28 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
                 pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
                 pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
 #if defined(KPEG_ABLATE_PUSH)
+#if KPEG_K4_MASK_MARKS
+                (void)mY, (void)mB, (void)mR, (void)mG, (void)kg;
+#else
                 (void)fy, (void)fb, (void)fr, (void)kg;   // timing experiment: no unsafe-pixel arithmetic survives
+#endif
+#else
+#if KPEG_K4_MASK_MARKS
+                (void)kg;
+                if (decltype(with_wide)::value) mG &= ~wide_mask;   // (their G comes from the reference's own arithmetic)
+                rowY |= mY, rowB |= mB, rowR |= mR, rowG |= mG;
+                {
+                    const unsigned long long mp = (mY | mB) | (mR | mG);
+                    unsigned long long carry;
+                    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(ubM), "=&s"(carry) : "s"(mp));   // ubM = ubM << 1 | the lane's bit of mp
+                }
 #else
                 // the signs into the four bytes: u << 1 | sign (one v_alignbit each, in place of the ANDs that used to merge them)
                 ubY = __builtin_amdgcn_alignbit(ubY, __float_as_uint(fy), 31);
                 ubB = __builtin_amdgcn_alignbit(ubB, __float_as_uint(fb), 31);
                 ubR = __builtin_amdgcn_alignbit(ubR, __float_as_uint(fr), 31);
                 ubG = __builtin_amdgcn_alignbit(ubG, kg, 31);
+#endif
                 if (i & 1) {
                     // two columns' rounded samples as an f16 pair (exact: integers, |.| <= 2048 wherever the bound is finite enough to matter;
                     // fx_flush treats a larger one as unsafe)
@@ -1281,9 +1326,20 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         {
             // One compare, one ballot: the tile loop's only test on what the pixel loop found.  The rows that have a marked pixel join the
             // queue, at ranks counted from the same ballot; the count is a scalar.
+#if KPEG_K4_MASK_MARKS
+            // the rows that have a mark: a scalar OR of the four masks, no vector compare and no wait for one
+            const unsigned long long mbal = ((rowY | rowB) | (rowR | rowG)) & __ballot(active);
+#else
             const uint32_t marked = active ? ~(ubY & ubB & ubR & ubG) & 0xFFu : 0u;   // bit 7 - i = pixel column i needs the reference-order evaluation
             const unsigned long long mbal = __ballot(marked != 0);
+#endif
             if (mbal) {   // wave-uniform: two tiles in five on the 8K workload
+#if KPEG_K4_MASK_MARKS
+                const uint32_t marked = ((mbal >> tid) & 1ull) ? ubM & 0xFFu : 0u;   // bit 7 - i = pixel column i needs the reference-order evaluation
+                // per component: bit 7 - i = pixel column i is vouched for -- every unmarked one, and the marked ones too unless the row has a mark of the component
+                const uint32_t ubY = ((rowY >> tid) & 1ull) ? ~marked : 0xFFu, ubB = ((rowB >> tid) & 1ull) ? ~marked : 0xFFu,
+                               ubR = ((rowR >> tid) & 1ull) ? ~marked : 0xFFu, ubG = ((rowG >> tid) & 1ull) ? ~marked & 0xFFu : 0xFFu;
+#endif
 #if !defined(KPEG_COUNT_NC) && !defined(KPEG_COUNT_NCTILES) && !defined(KPEG_COUNT_ROWS)
                 fx_lane += (uint32_t)__popc(marked);
 #elif defined(KPEG_COUNT_ROWS)
