@@ -1453,5 +1453,203 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
     status_epilogue(p.status, p.h_status, gridDim.x, p.keep_status, dep);
 }
 
+// ---- 4:2:0 (extension): fast path ------------------------------------------------------------------------------------------
+// What k_idct_colour_fast does for 4:4:4, for 16x16 MCUs of six blocks (Y00 Y01 Y10 Y11 Cb Cr, dense coefficient layout, a bound per
+// block from K2 as there).  One wavefront per tile of four MCUs (64 x 16 pixels), three passes of eight blocks, eight lanes per block as
+// in k_idct_colour_fast (block_fast: lane j of a group ends with sample row j of its block): first the tile's eight chroma blocks --
+// their rounded samples, and per sample whether it is within the block's bound of a rounding boundary, go to LDS -- then the luma
+// blocks of MCUs 0, 1 and those of MCUs 2, 3: lane j of luma block (by, bx) holds pixel row by * 8 + j, columns bx * 8 .. bx * 8 + 7
+// of its MCU, and reads chroma row (by * 8 + j) / 2, columns bx * 4 .. bx * 4 + 3 (a chroma sample covers 2 x 2 pixels, no
+// interpolation: k_idct_colour_exact_420 above is the definition).  The f32 colour arithmetic and its keys are k_idct_colour_fast's.
+// A pixel that has an untrusted sample (luma or chroma) or G term, and every pixel of an MCU whose chroma may leave the f32 colour
+// arithmetic's range, is settled at once in the finished tile in LDS, before the tile is written back: the lane evaluates the samples
+// concerned in the reference's order from the dense coefficients (exact_sample_lane) and converts with colour_exact.  No queue across
+// tiles: a marked pass costs a divergent round or two, which this extension can afford (the reference-order kernel it replaces
+// evaluates every sample that way).
+struct Idct420Params {
+    const int16_t* coef;    // [mcu][6][64] natural order
+    const float* ebound;    // [mcu][6] (block_ebound: magnitude = bound, lowest mantissa bit of a chroma block's = samples may leave +-249)
+    uint8_t* rgb;           // the picture padded to whole MCUs
+    uint32_t mcus_w, mcus_h, pitch, tiles_w, ntiles;
+    uint32_t* stats;        // [256] counters of pixels settled in the reference's order (may be null)
+};
+constexpr int T420_STRIDE = 208;   // bytes per tile row in LDS (192 + padding, as TILE_ROW_STRIDE)
+
+__global__ __launch_bounds__(256) void k_idct_colour_fast_420(Idct420Params p, QTables qt)
+{
+    __shared__ __attribute__((aligned(16))) float s_m[2][64];          // AC input scales, natural order
+    __shared__ __attribute__((aligned(16))) uint32_t s_qi[2 * 64];     // quantisers, natural order
+    __shared__ double s_cos[64];
+    __shared__ __attribute__((aligned(16))) float s_chr_all[4][8][8][8];   // [wavefront][chroma block of the tile][row][column] rounded samples (minus the level shift)
+    __shared__ uint32_t s_chf_all[4][64];                                  // [..][block * 8 + row] bit i: column i is untrusted; bit 8: the block's samples may leave the colour range
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile_all[4][16 * T420_STRIDE];
+
+    const int tid = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane8 = tid & 7, grp = tid >> 3;
+    const int u = lane8 < 4 ? 2 * lane8 : 2 * (lane8 - 4) + 1;   // coefficient row this lane loads
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x >> 6, k = threadIdx.x & 63;
+        s_m[t][k] = 0.25f * cc_of(k >> 3, k & 7) * (float)qt.q[t][k];
+        s_qi[t * 64 + k] = qt.q[t][k];
+    } else if (threadIdx.x < 192) {
+        s_cos[tid] = c_cos[tid];
+    }
+    LaneConst lc;
+    lc.q0[0] = (float)qt.q[0][u * 8];
+    lc.q0[1] = (float)qt.q[1][u * 8];
+    lc.cc0 = cc_of(u, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // the lane's column-pass constants (see k_idct_colour_fast)
+        float r = cosf_tab(1 * (2 * k));
+#pragma unroll
+        for (int l = 1; l < 8; ++l) {
+            const float c = l < 4 ? cosf_tab((2 * l + 1) * (2 * k)) : -cosf_tab((2 * (7 - l) + 1) * (2 * k + 1));
+            r = lane8 == l ? c : r;
+        }
+        lc.k[k] = r;
+    }
+    lc.s = lane8 < 4 ? -1.0f : 1.0f;
+    __syncthreads();
+    const uint32_t tile = blockIdx.x * 4u + (uint32_t)wave;
+    if (tile >= p.ntiles) return;   // wave-uniform (no barrier below)
+    float (*s_chr)[8][8] = s_chr_all[wave];
+    uint32_t* const s_chf = s_chf_all[wave];
+    uint8_t* const s_tile = s_tile_all[wave];
+    const uint32_t trow = tile / p.tiles_w, tcol = tile - trow * p.tiles_w;
+    const uint32_t m0 = tcol * 4u, nm = min(4u, p.mcus_w - m0);
+    const size_t mcu0 = (size_t)trow * p.mcus_w + m0;
+
+    // ---- the tile's chroma blocks: group g = block (g & 1 ? Cr : Cb) of MCU g >> 1
+    {
+        const uint32_t mt = (uint32_t)grp >> 1, mte = mt < nm ? mt : 0u;   // (MCUs beyond the picture read the tile's first one: never stored)
+        const size_t blk = (mcu0 + mte) * 6 + 4 + ((uint32_t)grp & 1u);
+        const uint4 d = reinterpret_cast<const uint4*>(p.coef + blk * 64)[u];
+        const float e = p.ebound[blk];
+        const bool big = __ballot(((d.z | d.w) | (u >= 4 ? (d.x | d.y) : 0u)) != 0) != 0;
+        float v[8];
+        if (big) block_fast<8>(d, lc, &s_m[1][u * 8], 1, v);
+        else block_fast<4>(d, lc, &s_m[1][u * 8], 1, v);
+        const float thr = 0.5f - fabsf(e);   // |v - rint v| >= thr: within the block's bound of a rounding boundary (a NaN counts)
+        uint32_t un = 0;
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            r[i] = __builtin_rintf(v[i]);
+            un |= !(fabsf(v[i] - r[i]) < thr) ? 1u << i : 0u;
+        }
+        float4* dst = reinterpret_cast<float4*>(&s_chr[grp][lane8][0]);
+        dst[0] = make_float4(r[0], r[1], r[2], r[3]);
+        dst[1] = make_float4(r[4], r[5], r[6], r[7]);
+        s_chf[grp * 8 + lane8] = un | ((__float_as_uint(e) & 1u) << 8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t settled = 0;
+    // ---- the luma blocks, two MCUs a pass: group g = block g & 3 (Y00 Y01 Y10 Y11) of MCU 2 * pass + (g >> 2)
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+        const uint32_t mt = pass * 2u + ((uint32_t)grp >> 2), mte = mt < nm ? mt : 0u;
+        const uint32_t yb = (uint32_t)grp & 3u, by = yb >> 1, bx = yb & 1u;
+        const size_t mcu = mcu0 + mte;
+        const uint4* const yrows = reinterpret_cast<const uint4*>(p.coef + (mcu * 6 + yb) * 64);
+        const uint4 d = yrows[u];
+        const float e = p.ebound[mcu * 6 + yb];
+        const bool big = __ballot((d.w | (u >= 6 ? (d.x | d.y | d.z) : 0u)) != 0) != 0;
+        float vy[8];
+        if (big) block_fast<8>(d, lc, &s_m[0][u * 8], 0, vy);
+        else block_fast<6>(d, lc, &s_m[0][u * 8], 0, vy);
+        const float thr = 0.5f - fabsf(e);
+        // the chroma samples of this lane's pixel row
+        const uint32_t cyr = by * 4u + ((uint32_t)lane8 >> 1);
+        const float4 cb4 = *reinterpret_cast<const float4*>(&s_chr[mte * 2][cyr][bx * 4]);
+        const float4 cr4 = *reinterpret_cast<const float4*>(&s_chr[mte * 2 + 1][cyr][bx * 4]);
+        const uint32_t fcb = s_chf[(mte * 2) * 8 + cyr], fcr = s_chf[(mte * 2 + 1) * 8 + cyr];
+        const float cbv[4] = {cb4.x, cb4.y, cb4.z, cb4.w}, crv[4] = {cr4.x, cr4.y, cr4.z, cr4.w};
+        uint32_t pk[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t my = 0, mg = 0;   // bit i: pixel column i has an untrusted luma sample / G term
+        float yo_prev = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float ry = __builtin_rintf(vy[i]);
+            my |= !(fabsf(vy[i] - ry) < thr) ? 1u << i : 0u;
+            const float rb = cbv[i >> 1], rr = crv[i >> 1];
+            // the colour arithmetic of k_idct_colour_fast's pixel loop (ranges and rounding argument: there, tests/test_tables.py)
+            const float yo = ry + 127.501f;
+            const float R = __builtin_fmaf(rr, 1.402f, yo);
+            const float B = __builtin_fmaf(rb, 1.772f, yo);
+            const float t = __builtin_fmaf(rr, 0.714136f, rb * 0.344136f);
+            const float tc = ceilf(t);
+            const float G = yo - tc;
+            if (!(i & 1)) {   // (t belongs to the pixel pair)
+                const bool gun = !(fabsf((tc - t) - 0.5f) < (0.5f - KPEG_G_DELTA)) && !(fabsf(t) < 4.0e-6f);   // within DELTA of a non-zero integer
+                mg |= gun ? 3u << i : 0u;
+            }
+            (void)yo_prev;
+            pk[(3 * i) >> 2] = pk_u8(R, (3 * i) & 3, pk[(3 * i) >> 2]);
+            pk[(3 * i + 1) >> 2] = pk_u8(G, (3 * i + 1) & 3, pk[(3 * i + 1) >> 2]);
+            pk[(3 * i + 2) >> 2] = pk_u8(B, (3 * i + 2) & 3, pk[(3 * i + 2) >> 2]);
+        }
+        uint8_t* const trow_lds = s_tile + (by * 8u + (uint32_t)lane8) * T420_STRIDE + (mt * 16u + bx * 8u) * 3u;
+        {
+            uint2* dst = reinterpret_cast<uint2*>(trow_lds);
+            dst[0] = make_uint2(pk[0], pk[1]);
+            dst[1] = make_uint2(pk[2], pk[3]);
+            dst[2] = make_uint2(pk[4], pk[5]);
+        }
+        // a chroma sample's flag covers two pixel columns
+        auto spread = [](uint32_t n4) -> uint32_t { return ((n4 & 1u) * 3u) | ((n4 & 2u) * 6u) | ((n4 & 4u) * 12u) | ((n4 & 8u) * 24u); };
+        const uint32_t mcb = spread((fcb >> (bx * 4u)) & 15u), mcr = spread((fcr >> (bx * 4u)) & 15u);
+        const bool wide = (((fcb | fcr) >> 8) & 1u) != 0;
+        uint32_t todo = mt < nm ? (wide ? 0xFFu : (my | mg | mcb | mcr)) : 0u;
+        if (__ballot(todo != 0)) {   // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            settled += (uint32_t)__popc(todo);
+            const uint4* const cbrows = reinterpret_cast<const uint4*>(p.coef + (mcu * 6 + 4) * 64);
+            const uint4* const crrows = reinterpret_cast<const uint4*>(p.coef + (mcu * 6 + 5) * 64);
+            while (__ballot(todo != 0)) {   // wave-uniform: a marked pixel of every lane per round
+                if (todo) {
+                    const uint32_t i = 31u - (uint32_t)__builtin_clz(todo);
+                    todo &= ~(1u << i);
+                    float fy = vy[0], fb = cbv[0], fr = crv[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) fy = i == (uint32_t)k ? vy[k] : fy;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) fb = (i >> 1) == (uint32_t)k ? cbv[k] : fb, fr = (i >> 1) == (uint32_t)k ? crv[k] : fr;
+                    int Sy = (int)__builtin_rintf(fy) + 128, Sb = (int)fb + 128, Sr = (int)fr + 128;
+                    const int cx = (int)cyr, cy = (int)(bx * 4u + (i >> 1));
+                    if ((my >> i) & 1u) Sy = exact_sample_lane(yrows, s_qi, s_cos, lane8, (int)i);
+                    if ((mcb >> i) & 1u) Sb = exact_sample_lane(cbrows, s_qi + 64, s_cos, cx, cy);
+                    if ((mcr >> i) & 1u) Sr = exact_sample_lane(crrows, s_qi + 64, s_cos, cx, cy);
+                    const uint32_t px = colour_exact(Sy, Sb, Sr);
+                    trow_lds[i * 3] = (uint8_t)px, trow_lds[i * 3 + 1] = (uint8_t)(px >> 8), trow_lds[i * 3 + 2] = (uint8_t)(px >> 16);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- write the tile back: 16 rows x nm * 48 bytes
+    uint8_t* const base = p.rgb + (size_t)trow * 16 * p.pitch + (size_t)m0 * 48;
+    if (nm == 4 && ((reinterpret_cast<uintptr_t>(p.rgb) | p.pitch) & 15) == 0) {
+#pragma unroll
+        for (uint32_t c = (uint32_t)tid; c < 16 * 12; c += 64) {
+            const uint32_t r = c / 12u, k = c - r * 12u;
+            __builtin_nontemporal_store(*reinterpret_cast<const uint4v*>(s_tile + r * T420_STRIDE + k * 16), reinterpret_cast<uint4v*>(base + (size_t)r * p.pitch + k * 16));
+        }
+    } else {
+        const uint32_t per_row = nm * 12;   // 4-byte pieces
+        for (uint32_t c = (uint32_t)tid; c < 16 * per_row; c += 64) {
+            const uint32_t r = c / per_row, k = c - r * per_row;
+            *reinterpret_cast<uint32_t*>(base + (size_t)r * p.pitch + k * 4) = *reinterpret_cast<const uint32_t*>(s_tile + r * T420_STRIDE + k * 4);
+        }
+    }
+    if (p.stats) {
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(settled), 63);
+        if (n && tid == 0) atomicAdd(&p.stats[blockIdx.x & 255], n);
+    }
+}
+
 
 }  // namespace kpeg_dev

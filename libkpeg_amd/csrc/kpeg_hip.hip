@@ -684,8 +684,8 @@ static int decode_any_size(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t
     return KPEG_HIP_OK;
 }
 
-// 4:2:0 extension: K0-K2 with six blocks per MCU, the reference-order kernel on 16x16 MCUs into the padded picture, crop.
-// (No fast path yet: every sample is evaluated in the reference's order -- exact by construction, about 8 Mpixel/ms.)
+// 4:2:0 extension: K0-K2 with six blocks per MCU, k_idct_colour_fast_420 on 16x16 MCUs into the padded picture (idct mode 1: the
+// reference-order kernel, every sample evaluated as MCU::computeIDCT would), crop.
 static int decode_420(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint8_t* d_rgb)
 {
     int rc = check_frame(ctx, f, true);
@@ -708,8 +708,17 @@ static int decode_420(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_s
     if (rc) return rc;
     QTables qt;
     natural_qtables(f, &qt);
-    hipLaunchKernelGGL(k_idct_colour_exact_420, dim3((unsigned)nmcu), dim3(256), 0, ctx->stream, (const int16_t*)ctx->d_coef, (uint8_t*)ctx->d_pad,
-                       mw, mw * 48, qt);
+    if (ctx->idct_mode == 1) {
+        // cross-check: every sample in the reference's order
+        hipLaunchKernelGGL(k_idct_colour_exact_420, dim3((unsigned)nmcu), dim3(256), 0, ctx->stream, (const int16_t*)ctx->d_coef, (uint8_t*)ctx->d_pad,
+                           mw, mw * 48, qt);
+    } else {
+        Idct420Params p;
+        p.coef = (const int16_t*)ctx->d_coef, p.ebound = (const float*)ctx->d_ebound, p.rgb = (uint8_t*)ctx->d_pad;
+        p.mcus_w = mw, p.mcus_h = mh, p.pitch = mw * 48, p.tiles_w = (mw + 3) / 4, p.ntiles = p.tiles_w * mh;
+        p.stats = ctx->d_status + 16;
+        hipLaunchKernelGGL(k_idct_colour_fast_420, dim3((p.ntiles + 3) / 4), dim3(256), 0, ctx->stream, p, qt);
+    }
     const uint64_t total = (uint64_t)f->width * f->height * 3;
     hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_pad, mw * 48, d_rgb,
                        f->width * 3, total);

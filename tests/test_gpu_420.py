@@ -56,6 +56,44 @@ def test_large_synthetic_pictures_match_the_oracle(ctx, w, h):
     _check(ctx, encode420(np.clip(px, 0, 255).astype(np.uint8), quality=80))
 
 
+@pytest.mark.parametrize("case", ["photo_q92", "noise_q12", "ramps_q60", "flat"])
+def test_fast_kernel_against_the_reference_order_kernel(ctx, case):
+    """k_idct_colour_fast_420 (idct mode 0, the default) against k_idct_colour_exact_420 (mode 1: every sample in the reference's
+    order) and the oracle: photographs (ties in the chroma blocks), black-and-white noise at quality 12 (large coefficients under coarse quantisers: chroma outside the f32
+    colour arithmetic's range, blocks whose bound is infinite), ramps (structural ties), a flat picture (no AC term anywhere)."""
+    pytest.importorskip("PIL.Image")
+    import libkpeg_amd as K
+    rng = np.random.default_rng(5)
+    if case == "photo_q92":
+        data = encode420(_photo()[:424, :640], quality=92)
+    elif case == "noise_q12":
+        data = encode420((rng.integers(0, 2, (232, 328, 3)) * 255).astype(np.uint8), quality=12)   # black and white: the largest coefficients there are, coarse quantisers
+    elif case == "ramps_q60":
+        y, x = np.mgrid[0:200, 0:333]
+        data = encode420(np.stack([(x * 2) % 256, (y * 3) % 256, (x + y) % 256], -1).astype(np.uint8), quality=60)
+    else:
+        data = encode420(np.full((64, 80, 3), (200, 30, 90), np.uint8), quality=75)
+    st, want = T.oracle_decode_420(data)
+    assert st == T.DECODE_DONE
+    rc, frame, scan = K.host_parse(data, allow_420=True)
+    assert rc == K.DECODE_DONE
+    try:
+        ctx.set_idct_mode(0)
+        fast = ctx.decode_scan(frame, scan)
+        settled = ctx.timings()["exact_pixels"]
+        ctx.set_idct_mode(1)
+        exact = ctx.decode_scan(frame, scan)
+    finally:
+        ctx.set_idct_mode(0)
+    assert np.array_equal(exact, want)
+    bad = np.argwhere(fast != want)
+    assert bad.size == 0, "first mismatches (y,x,c) %s of %d" % (bad[:8].tolist(), len(bad))
+    if case != "flat":
+        assert 0 < settled < want.shape[0] * want.shape[1] * (1.01 if case == "noise_q12" else 0.2), settled   # some pixels took the reference-order path, not all of them
+    else:
+        assert settled == 0
+
+
 def test_both_sub_sequence_sizes(ctx):
     """4:2:0 streams take the 384-bit sub-sequences by default; the 96-bit kernels are the same code and must agree."""
     pytest.importorskip("PIL.Image")
