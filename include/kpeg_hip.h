@@ -71,7 +71,7 @@ typedef struct kpeg_frame {
                                    KPEG_FRAME_420 = Y Cb Cr 4:2:0 (extension, off by default in the host parser: the
                                    reference answers TERMINATE on sampling factors other than 1x1): 16x16 MCUs of six
                                    blocks through the same per-block arithmetic, every chroma sample repeated 2x2;
-                                   whole-image entry points only, any width / height                                    */
+                                   whole-image and batch entry points, any width / height                               */
 } kpeg_frame;
 
 /* Per-call device timings (milliseconds, HIP events on the context's stream between the kernels, so a span is a kernel
@@ -136,12 +136,14 @@ int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const int16
  *         the FF D9; still byte-stuffed. */
 int kpeg_hip_decode_scan(kpeg_hip_ctx* ctx, const kpeg_frame* frame, const uint8_t* scan, size_t scan_len,
                          uint8_t* rgb);
-/* Extension (off by default in the host parser, KPEG_PARSE_ALLOW_ANY_SIZE): kpeg_hip_decode_scan, _scan_dev, _scan_resident
- * and kpeg_hip_download_bands also take widths / heights that are not multiples of 8.  All ceil(w/8) * ceil(h/8) MCUs of
+/* Extension (off by default in the host parser, KPEG_PARSE_ALLOW_ANY_SIZE): kpeg_hip_decode_scan, _scan_dev, _scan_resident,
+ * kpeg_hip_download_bands, kpeg_hip_decode_stripe_dev (MCU rows of the padded picture; a stripe's last pixel rows are the
+ * picture's) and kpeg_hip_decode_batch, _batch_dev also take widths / heights that are not multiples of 8.  All ceil(w/8) * ceil(h/8) MCUs of
  * the padded picture are decoded and the rows and columns Image::createImageFromMCUs pops (Image.cpp:26-27,73-84) are
  * cropped on the device; rgb is height*width*3 bytes as ever.  (The reference itself decodes (w*h)/64 MCUs and tiles
  * more than it has: undefined behaviour, so nothing to be bit-identical with but its output for the same scan at the
- * padded size -- which is what the tests pin.)  Every other entry point keeps the multiple-of-8 contract. */
+ * padded size -- which is what the tests pin.)  The kernels' own entry points (kpeg_hip_entropy_decode_dev, kpeg_hip_idct_colour*)
+ * and the sharded ones work on whole blocks and keep the multiple-of-8 contract. */
 
 /* The number of calls that have written pixels into the context's resident buffer so far.  A caller that leaves a decoded image
  * there (kpeg_hip_decode_scan_resident) notes it and checks it before kpeg_hip_download_bands: any later decode, batch or

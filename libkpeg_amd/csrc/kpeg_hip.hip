@@ -606,8 +606,9 @@ extern "C" int kpeg_hip_entropy_decode_dev(kpeg_hip_ctx* ctx, const kpeg_frame* 
     return finish_async(ctx, false);
 }
 
-extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len,
-                                          uint32_t first_mcu_row, uint32_t mcu_rows, uint8_t* d_rgb)
+// MCU rows [first_mcu_row, first_mcu_row + mcu_rows) of a picture of whole 8x8 MCUs
+static int decode_stripe_whole_mcus(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len,
+                                    uint32_t first_mcu_row, uint32_t mcu_rows, uint8_t* d_rgb)
 {
     int rc = check_frame(ctx, f);
     if (rc) return rc;
@@ -638,6 +639,41 @@ extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f
     return finish_async(ctx, ctx->idct_mode != 1);
 }
 
+__global__ void k_crop(const uint8_t* __restrict__ src, uint32_t spitch, uint8_t* __restrict__ dst, uint32_t dpitch, uint64_t total);
+
+// Any-size extension at the stripe entry: the stripe's MCU rows of the padded picture go to scratch, the rows and columns the picture
+// has are packed into d_rgb (the stripe's first pixel row, rows of 3 * width bytes).
+extern "C" int kpeg_hip_decode_stripe_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len,
+                                          uint32_t first_mcu_row, uint32_t mcu_rows, uint8_t* d_rgb)
+{
+    if (!ctx || !f) return KPEG_HIP_E_ARG;
+    if (f->components == KPEG_FRAME_420) {
+        ctx->last_error = "4:2:0 pictures are decoded whole (kpeg_hip_decode_scan*, kpeg_hip_decode_batch*), not in stripes";
+        return KPEG_HIP_E_UNSUPPORTED;
+    }
+    if (!((f->width & 7) || (f->height & 7))) return decode_stripe_whole_mcus(ctx, f, d_scan, scan_len, first_mcu_row, mcu_rows, d_rgb);
+    int rc = check_frame(ctx, f, true);
+    if (rc) return rc;
+    kpeg_frame fp = *f;
+    fp.width = (f->width + 7) & ~7u;
+    fp.height = (f->height + 7) & ~7u;
+    if (!d_scan || !scan_len || !d_rgb || mcu_rows == 0 || first_mcu_row + mcu_rows > fp.height / 8) return KPEG_HIP_E_ARG;
+    if (reinterpret_cast<uintptr_t>(d_rgb) & 7) {
+        ctx->last_error = "rgb buffer must be 8-byte aligned";
+        return KPEG_HIP_E_ARG;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((rc = grow(ctx, &ctx->d_pad, &ctx->pad_cap, (size_t)fp.width * 3 * mcu_rows * 8))) return rc;
+    rc = decode_stripe_whole_mcus(ctx, &fp, d_scan, scan_len, first_mcu_row, mcu_rows, (uint8_t*)ctx->d_pad);
+    if (rc) return rc;
+    const uint32_t out_rows = std::min(mcu_rows * 8, f->height - first_mcu_row * 8);
+    const uint64_t total = (uint64_t)f->width * 3 * out_rows;
+    hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_pad, fp.width * 3,
+                       d_rgb, f->width * 3, total);
+    HIPCHK(ctx, hipGetLastError());
+    return KPEG_HIP_OK;
+}
+
 // Any-size extension (Image::createImageFromMCUs, Image.cpp:26-27,73-84: pad to whole MCUs, tile, pop the extra columns
 // and rows): rows [0, H) x bytes [0, 3 W) of the padded picture, four destination bytes per thread.
 __global__ void k_crop(const uint8_t* __restrict__ src, uint32_t spitch, uint8_t* __restrict__ dst, uint32_t dpitch, uint64_t total)
@@ -663,25 +699,7 @@ __global__ void k_crop(const uint8_t* __restrict__ src, uint32_t spitch, uint8_t
 
 static int decode_any_size(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_scan, size_t scan_len, uint8_t* d_rgb)
 {
-    int rc = check_frame(ctx, f, true);
-    if (rc) return rc;
-    if (!d_scan || !scan_len || !d_rgb) return KPEG_HIP_E_ARG;
-    if (reinterpret_cast<uintptr_t>(d_rgb) & 7) {
-        ctx->last_error = "rgb buffer must be 8-byte aligned";
-        return KPEG_HIP_E_ARG;
-    }
-    kpeg_frame fp = *f;
-    fp.width = (f->width + 7) & ~7u;
-    fp.height = (f->height + 7) & ~7u;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if ((rc = grow(ctx, &ctx->d_pad, &ctx->pad_cap, (size_t)fp.width * fp.height * 3))) return rc;
-    rc = kpeg_hip_decode_stripe_dev(ctx, &fp, d_scan, scan_len, 0, fp.height / 8, (uint8_t*)ctx->d_pad);
-    if (rc) return rc;
-    const uint64_t total = (uint64_t)f->width * f->height * 3;
-    hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_pad, fp.width * 3,
-                       d_rgb, f->width * 3, total);
-    HIPCHK(ctx, hipGetLastError());
-    return KPEG_HIP_OK;
+    return kpeg_hip_decode_stripe_dev(ctx, f, d_scan, scan_len, 0, (f->height + 7) / 8, d_rgb);
 }
 
 // 4:2:0 extension: K0-K2 with six blocks per MCU, k_idct_colour_fast_420 on 16x16 MCUs into the padded picture (idct mode 1: the
@@ -966,11 +984,41 @@ static int decode_batch_fused(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f,
 extern "C" int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f, const uint8_t* const* d_scans,
                                          const size_t* scan_lens, uint8_t* const* d_rgbs)
 {
-    int rc = check_frame(ctx, f);
+    int rc = check_frame(ctx, f, true);
     if (rc) return rc;
     if (count <= 0 || !d_scans || !scan_lens || !d_rgbs) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!f->restart_interval && ctx->idct_mode != 1) return decode_batch_fused(ctx, count, f, d_scans, scan_lens, d_rgbs);
+    const bool odd = (f->width & 7) || (f->height & 7), s420 = f->components == KPEG_FRAME_420;
+    if (!f->restart_interval && ctx->idct_mode != 1 && !s420) {
+        if (!odd) return decode_batch_fused(ctx, count, f, d_scans, scan_lens, d_rgbs);
+        // any-size extension: the padded pictures through the fused path into scratch, up to 1 GiB of them at a time, then the
+        // rows and columns the pictures have are packed into the callers' buffers
+        kpeg_frame fp = *f;
+        fp.width = (f->width + 7) & ~7u;
+        fp.height = (f->height + 7) & ~7u;
+        const size_t pb = (size_t)fp.width * fp.height * 3;   // (a multiple of 16: the fused path's alignment rule holds for every picture)
+        const int per = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)1 << 30) / pb));
+        const uint64_t total = (uint64_t)f->width * f->height * 3;
+        for (int done = 0; done < count; done += per) {
+            const int n = std::min(per, count - done);
+            for (int i = 0; i < n; ++i)
+                if (!d_rgbs[done + i] || (reinterpret_cast<uintptr_t>(d_rgbs[done + i]) & 7)) {
+                    ctx->last_error = "batch: rgb buffers must be 8-byte aligned";
+                    return KPEG_HIP_E_ARG;
+                }
+            if (done && (rc = kpeg_hip_sync(ctx))) return rc;   // the scratch is the previous pictures' until their crops have run
+            if ((rc = grow(ctx, &ctx->d_pad, &ctx->pad_cap, pb * n))) return rc;
+            std::vector<uint8_t*> pads(n);
+            for (int i = 0; i < n; ++i) pads[i] = (uint8_t*)ctx->d_pad + pb * i;
+            if ((rc = decode_batch_fused(ctx, n, &fp, d_scans + done, scan_lens + done, pads.data()))) return rc;
+            for (int i = 0; i < n; ++i)
+                hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)pads[i], fp.width * 3,
+                                   d_rgbs[done + i], f->width * 3, total);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        return KPEG_HIP_OK;
+    }
+    // restart markers inside the pictures, 4:2:0, the reference-order kernel: picture by picture, round-robin over the lanes
     if ((rc = ensure_lanes(ctx))) return rc;
     if ((rc = lanes_fork(ctx))) return rc;
     for (int i = 0; i < count; ++i) {
@@ -988,13 +1036,13 @@ extern "C" int kpeg_hip_decode_batch_dev(kpeg_hip_ctx* ctx, int count, const kpe
 extern "C" int kpeg_hip_decode_batch(kpeg_hip_ctx* ctx, int count, const kpeg_frame* f, const uint8_t* const* scans,
                                      const size_t* scan_lens, uint8_t* const* rgbs)
 {
-    int rc = check_frame(ctx, f);
+    int rc = check_frame(ctx, f, true);
     if (rc) return rc;
     if (count <= 0 || !scans || !scan_lens || !rgbs) return KPEG_HIP_E_ARG;
     for (int i = 0; i < count; ++i)
         if (!scans[i] || !scan_lens[i] || !rgbs[i]) return KPEG_HIP_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (f->restart_interval || ctx->idct_mode == 1) {
+    if (f->restart_interval || ctx->idct_mode == 1 || (f->width & 7) || (f->height & 7) || f->components == KPEG_FRAME_420) {
         // outside the fused path's contract: one by one
         for (int i = 0; i < count; ++i)
             if ((rc = kpeg_hip_decode_scan(ctx, f, scans[i], scan_lens[i], rgbs[i]))) return rc;

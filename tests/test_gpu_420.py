@@ -149,19 +149,29 @@ def test_corrupt_420_streams_report_and_recover(ctx):
     assert np.array_equal(ctx.decode_scan(frame, scan), want)
 
 
-def test_other_entry_points_reject_420(ctx):
+def test_batch_entry_points_take_420_and_the_stripe_entry_rejects_it(ctx):
+    """Batches decode 4:2:0 pictures one by one (round-robin over the context's lanes; host buffers: picture by picture); a stripe of
+    a 4:2:0 picture is not offered."""
     import torch
     import libkpeg_amd as K
     pytest.importorskip("PIL.Image")
-    data = encode420(_photo()[:64, :64], quality=85)
-    rc, frame, scan = K.host_parse(data, allow_420=True)
-    d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
-    d_rgb = torch.zeros((64, 64, 3), dtype=torch.uint8, device="cuda")
+    files = [encode420(_photo()[k * 16:k * 16 + 75, k * 8:k * 8 + 101], quality=85) for k in range(4)]
+    wants = [T.oracle_decode_420(d)[1] for d in files]
+    parsed = [K.host_parse(d, allow_420=True) for d in files]
+    frame = parsed[0][1]
+    scans = [np.ascontiguousarray(sc) for _, _, sc in parsed]
+    d_scans = [torch.from_numpy(sc).cuda() for sc in scans]
+    d_rgbs = [torch.zeros((75, 101, 3), dtype=torch.uint8, device="cuda") for _ in files]
+    torch.cuda.synchronize()
+    ctx.decode_batch_dev(frame, [t.data_ptr() for t in d_scans], [t.numel() for t in d_scans], [t.data_ptr() for t in d_rgbs])
+    ctx.sync()
+    for k in range(len(files)):
+        assert np.array_equal(d_rgbs[k].cpu().numpy(), wants[k]), k
+    outs = ctx.decode_batch(frame, scans)
+    for k in range(len(files)):
+        assert np.array_equal(outs[k], wants[k]), k
     with pytest.raises(K.KpegError) as e:
-        ctx.decode_stripe_dev(frame, d_scan.data_ptr(), d_scan.numel(), 0, 8, d_rgb.data_ptr())
-    assert e.value.code == K.E_UNSUPPORTED
-    with pytest.raises(K.KpegError) as e:
-        ctx.decode_batch_dev(frame, [d_scan.data_ptr()], [d_scan.numel()], [d_rgb.data_ptr()])
+        ctx.decode_stripe_dev(frame, d_scans[0].data_ptr(), d_scans[0].numel(), 0, 8, d_rgbs[0].data_ptr())
     assert e.value.code == K.E_UNSUPPORTED
 
 
