@@ -787,79 +787,82 @@ __device__ KPEG_FX_MANY_ATTR void fx_noncorner_many(lds_u32* entry, lds_cu32* im
 // what is still unsafe in an entry belongs to a corner-only block (fx_noncorner_* have settled the rest).
 __device__ __attribute__((noinline)) void fx_flush(FxArgs a, lds_cu32* q, uint32_t nrows, lds_cu32* s_qi, lds_cf64* s_cos)
 {
+    // ONE LANE PER MARKED PIXEL (the round's first build gave a lane a row and went round as often as the fullest row had marked
+    // pixels, every round through all three components' code): the queue's marked pixels are numbered in row order, a row's from
+    // its highest bit down, and pixel number i goes to lane i mod 64 -- the row it sits in is found by a binary search over the rows'
+    // running counts (ds_bpermute, as fx_noncorner_many) -- and a lane evaluates just the components its pixel needs.
     const uint32_t lane = (uint32_t)__lane_id();
     const bool have = lane < nrows;
     const float c0 = 0x1.6a09e6p-1f;
-    // this lane's row
-    uint32_t hs[12], keys = 0xFFFFFFFFu, where = 0, cw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-    {
-        lds_cu32* e = q + lane * ROWQ_WORDS;
+    const uint32_t keys = have ? q[lane * ROWQ_WORDS + 12] : 0xFFFFFFFFu;
+    const uint32_t todo = ~(keys & (keys >> 8) & (keys >> 16) & (keys >> 24)) & 0xFFu;   // bit 7 - i: pixel column i of the row is marked
+    const uint32_t cnt = (uint32_t)__popc(todo), incl = wave_scan_incl(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    for (uint32_t base = 0; base < total; base += 64) {   // wave-uniform: once, unless more than 64 pixels have gathered
+        const uint32_t i = base + lane;
+        const bool act = i < total;
+        uint32_t owner = 0;   // rows whose running count is <= i
 #pragma unroll
-        for (int k = 0; k < 12; ++k) hs[k] = have ? e[k] : 0u;
-        if (have) {
-            keys = e[12], where = e[13];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cw[k] = e[14 + k];
+        for (uint32_t s = 32; s; s >>= 1) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((owner + s - 1) << 2), (int)incl);
+            owner += v <= i ? s : 0u;
         }
-    }
-    const uint32_t tile = min(where >> 6, a.ntiles - 1), Lt = where & 63u;
-    const uint32_t g = Lt >> 3, x = Lt & 7u;   // MCU of the tile, pixel row
-    const uint32_t trow = a.tiles_w == 1 ? tile : (__umulhi(tile, a.tiles_w_magic) >> a.tiles_w_shift), tcol = tile - trow * a.tiles_w;
-    const uint32_t m0 = tcol * TILE_MCUS;
-    uint32_t todo = have ? ~(keys & (keys >> 8) & (keys >> 16) & (keys >> 24)) & 0xFFu : 0u;   // bit 7 - i: pixel column i is marked
-    // the pixel's bytes in the picture
-    size_t rowoff;
-    {
-        size_t off;
-        if (a.rgb_table) {
-            const uint32_t img = trow / a.rows_per_img;
-            off = (todo ? (size_t)(reinterpret_cast<uintptr_t>(a.rgb_table[img]) - reinterpret_cast<uintptr_t>(a.rgb)) : 0) + (size_t)(trow - img * a.rows_per_img) * 8 * a.pitch;
-        } else {
-            off = (size_t)trow * 8 * a.pitch;
+        owner = act ? owner : 63u;
+        uint32_t kth = i - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)(incl - cnt));
+        uint32_t bits = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)todo);
+        const uint32_t okeys = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)keys);
+        kth = act ? kth : 0u;
+        while (__ballot(kth != 0)) {   // wave-uniform: at most seven rounds of three instructions
+            if (kth) {
+                bits &= ~(1u << (31u - (uint32_t)__builtin_clz(bits)));
+                --kth;
+            }
         }
-        rowoff = off + (size_t)x * a.pitch + (size_t)(m0 + g) * 24;
-    }
-    lds_cf64* const cx = s_cos + x * 8;
-    // a pixel of every row per round
-    while (__ballot(todo != 0)) {   // wave-uniform
-        const bool act = todo != 0;
-        const uint32_t bit = act ? 31u - (uint32_t)__builtin_clz(todo) : 7u;   // highest marked bit first: pixel column 7 - bit
-        todo &= ~(1u << bit);
-        const uint32_t y = 7u - bit;
-        lds_cf64* const cy = s_cos + y * 8;
-        // the pixel's rounded fast samples: half y & 1 of word y >> 1 of every component
+        if (!(act && bits)) continue;   // (lanes without a pixel sit the rest out; nothing below is wave-wide)
+        const uint32_t bit = 31u - (uint32_t)__builtin_clz(bits), y = 7u - bit;
+        lds_cu32* const e = q + owner * ROWQ_WORDS;
+        const uint32_t where = e[13];
+        // the pixel's rounded fast samples
+        const __attribute__((address_space(3))) uint16_t* const eh = reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>(e);
         int S[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            uint32_t w = hs[c * 4];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) w = (y >> 1) == (uint32_t)k ? hs[c * 4 + k] : w;
-            const uint16_t hb = (uint16_t)((y & 1u) ? w >> 16 : w & 0xFFFFu);
-            S[c] = (int)(float)__builtin_bit_cast(_Float16, hb) + 128;
-        }
-        const uint32_t need = !act ? 0u : ((((keys >> bit) & 1u) ? 0u : 1u) | (((keys >> (8 + bit)) & 1u) ? 0u : 2u) | (((keys >> (16 + bit)) & 1u) ? 0u : 4u));
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (!(need & (1u << c))) continue;
-            lds_cu32* qi = s_qi + (c ? 64 : 0);
-            // MCU::computeIDCT's sum (MCU.cpp:184-198) for a block that has nothing outside (0,0), (0,1), (1,0), (1,1), in its order; a
-            // zero term leaves the float accumulator as it is (x + (+-0) == x), so none needs a test.  cos((2x+1) 0 pi/16) == 1.0 exactly.
-            const uint32_t wa = cw[2 * c], wb = cw[2 * c + 1];
+        for (int c = 0; c < 3; ++c) S[c] = (int)(float)__builtin_bit_cast(_Float16, eh[c * 8 + y]) + 128;
+        const uint32_t x = where & 7u;   // pixel row
+        lds_cf64* const cx = s_cos + x * 8;
+        lds_cf64* const cy = s_cos + y * 8;
+        // the components the entry does not vouch for: MCU::computeIDCT's sum (MCU.cpp:184-198) for a block that has nothing outside
+        // (0,0), (0,1), (1,0), (1,1), in its order; a zero term leaves the float accumulator as it is (x + (+-0) == x), so none needs a
+        // test.  cos((2x+1) 0 pi/16) == 1.0 exactly.  (fx_noncorner_* have settled what sits in other blocks.)
+        uint32_t need = (((okeys >> bit) & 1u) ? 0u : 1u) | (((okeys >> (8 + bit)) & 1u) ? 0u : 2u) | (((okeys >> (16 + bit)) & 1u) ? 0u : 4u);
+        while (need) {   // per lane: nearly always one component
+            const uint32_t c = (uint32_t)__builtin_ctz(need);
+            need &= need - 1u;
+            lds_cu32* const qi = s_qi + (c ? 64 : 0);
+            const uint32_t wa = e[14 + 2 * c], wb = e[15 + 2 * c];
             const float fc00 = (c0 * c0) * (float)((int)(short)(wa & 0xFFFF) * (int)qi[0]), fc01 = (c0 * 1.0f) * (float)(((int)wa >> 16) * (int)qi[1]),
                         fc10 = (1.0f * c0) * (float)((int)(short)(wb & 0xFFFF) * (int)qi[8]), fc11 = (float)(((int)wb >> 16) * (int)qi[9]);
             float sum = fc00;
             sum = (float)((double)sum + (double)fc01 * cy[1]);
             sum = (float)((double)sum + (double)fc10 * cx[1]);
             sum = (float)((double)sum + ((double)fc11 * cx[1]) * cy[1]);
-            S[c] = level_shift((float)(0.25 * (double)sum));
+            const int v = level_shift((float)(0.25 * (double)sum));
+            S[0] = c == 0 ? v : S[0], S[1] = c == 1 ? v : S[1], S[2] = c == 2 ? v : S[2];
         }
-        if (act) {
-            const uint32_t px = colour_exact(S[0], S[1], S[2]);
-            uint8_t* o = a.rgb + rowoff + y * 3;
-            o[0] = (uint8_t)px;
-            o[1] = (uint8_t)(px >> 8);
-            o[2] = (uint8_t)(px >> 16);
+        const uint32_t px = colour_exact(S[0], S[1], S[2]);
+        // the pixel's bytes in the picture
+        const uint32_t tile = min(where >> 6, a.ntiles - 1), g = (where >> 3) & 7u;   // MCU of the tile
+        const uint32_t trow = a.tiles_w == 1 ? tile : (__umulhi(tile, a.tiles_w_magic) >> a.tiles_w_shift), tcol = tile - trow * a.tiles_w;
+        size_t off;
+        if (a.rgb_table) {
+            const uint32_t img = trow / a.rows_per_img;
+            off = (size_t)(reinterpret_cast<uintptr_t>(a.rgb_table[img]) - reinterpret_cast<uintptr_t>(a.rgb)) + (size_t)(trow - img * a.rows_per_img) * 8 * a.pitch;
+        } else {
+            off = (size_t)trow * 8 * a.pitch;
         }
+        uint8_t* const o = a.rgb + off + (size_t)x * a.pitch + (size_t)(tcol * TILE_MCUS + g) * 24 + y * 3;
+        o[0] = (uint8_t)px;
+        o[1] = (uint8_t)(px >> 8);
+        o[2] = (uint8_t)(px >> 16);
     }
 }
 

@@ -260,13 +260,17 @@ def test_bad_arguments(ctx):
     data = T.synth_jpeg(64, 64, seed=1)
     p = T.oracle_parse(data)
     f = T.make_frame(p)
-    f.width = 60  # not a multiple of 8: the reference reads out of bounds here; only the whole-image entry points take it
-    # (any-size extension, tests/test_gpu_any_size.py) -- the stripe, batch and per-kernel entry points keep the contract
+    f.width = 60  # not a multiple of 8: the reference reads out of bounds here; the whole-image, stripe and batch entry points take it
+    # as the any-size extension (tests/test_gpu_any_size.py) -- the kernels' own entry points work on whole blocks and keep the contract
     import torch
     d_scan = torch.from_numpy(np.frombuffer(p.scan, np.uint8).copy()).cuda()
+    d_coef = torch.zeros(64 * 192, dtype=torch.int16, device="cuda")
     d_rgb = torch.zeros((64, 64, 3), dtype=torch.uint8, device="cuda")
     with pytest.raises(K.KpegError) as e:
-        ctx.decode_stripe_dev(f, d_scan.data_ptr(), d_scan.numel(), 0, 8, d_rgb.data_ptr())
+        ctx.entropy_decode_dev(f, d_scan.data_ptr(), d_scan.numel(), d_coef.data_ptr())
+    assert e.value.code == K.E_ARG
+    with pytest.raises(K.KpegError) as e:
+        ctx.decode_stripe_dev(f, d_scan.data_ptr(), d_scan.numel(), 0, 9, d_rgb.data_ptr())   # past the picture's last MCU row
     assert e.value.code == K.E_ARG
     f.width = 0
     with pytest.raises(K.KpegError) as e:
