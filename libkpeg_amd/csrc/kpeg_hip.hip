@@ -529,7 +529,12 @@ static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t 
     // per block -- 100 bytes of records against 128 + 128 (clear) of dense coefficients -- and K2's consecutive 4-byte records cost
     // it 0.174 ms where the scattered 2-byte stores cost 0.223 (K4 0.127 against 0.110: the rebuild in LDS grows with the records);
     // the whole decode 0.591 -> 0.556 ms (round 3, profiles/r03_e).  Beyond that the records outgrow the blocks.
-    if (nmcu * 384 <= ((uint64_t)32 << 20)) return false;
+    // Small pictures (up to 32 MiB of dense coefficients), since the end of round 3: the compact stream where the sub-sequences are
+    // the short ones -- it is what lets K1's pass 0 and K2 run as one kernel (k_sync_write), two launches less on pictures that are
+    // all launch gaps and latency chains: 512x512 ... 2560x1440 synthetic 4-9 % faster, lena.jpg the same, a 640x424 photograph at
+    // 3.5 bit/px 0.162 -> 0.145 ms; with the long sub-sequences (from 4 bits per pixel there) the dense layout stays ahead by 2 %
+    // (tools/small_images_layout.py, profiles/r03_l_small_pictures_layout.txt).
+    if (nmcu * 384 <= ((uint64_t)32 << 20)) return !dense;
     return !dense || scan_bytes * 8 < nmcu * 64 * 5;
 }
 

@@ -119,6 +119,7 @@ import numpy as np, kpeg_testlib as T, libkpeg_amd as K
 ctx = K.Context(0)
 assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, 64) == 0
 assert ctx.lib.kpeg_hip_debug_set(ctx._h, 2, 0) == 0      # no warm-up: every workgroup guesses wrong, the chained pass ripples
+assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 1) == 0      # the dense layout: the separate launches (small pictures take the one kernel otherwise)
 data = T.synth_jpeg(1024, 512, seed=21, quality=95, sigma=0.0, mode=1)
 st, want = T.oracle_decode(data)
 p = T.oracle_parse(data)
