@@ -78,6 +78,15 @@ namespace kpeg_dev {
 // the stream's bit rate: 96 (best on the 8K q75 workload, ~1 bit per pixel) and 384 for dense streams (from
 // 3 bits per pixel: they re-synchronise over thousands of bits, and fewer, longer rounds halve K1's time).
 constexpr int SUBSEQ_SPARSE = KPEG_SUBSEQ_BITS, SUBSEQ_DENSE = KPEG_SUBSEQ_BITS_DENSE;
+// A third size since the end of round 3, for SMALL sparse pictures: a picture of a few megapixels is a handful of workgroups on a
+// chip of 256 CUs, and what it costs is the length of one lane's chain of symbols -- decoded three times over (K1's exit states,
+// K1's counts, K2) at ~0.85 us a symbol when nothing else hides the latencies.  64-bit sub-sequences are two thirds of that chain:
+// 512x512 ... 2560x1440 at 1 bit/px 9-12 % faster end to end, photographs of 640x424 at 1-1.4 bit/px 13-14 %; from ~3 bits per pixel
+// the extra rounds cost more than the shorter chain saves (tools/small_images_layout.py, profiles/r03_l_small_pictures_layout.txt).
+#ifndef KPEG_SUBSEQ_BITS_SMALL
+#define KPEG_SUBSEQ_BITS_SMALL 64
+#endif
+constexpr int SUBSEQ_SMALL = KPEG_SUBSEQ_BITS_SMALL < KPEG_SUBSEQ_BITS ? KPEG_SUBSEQ_BITS_SMALL : KPEG_SUBSEQ_BITS;   // (== SUBSEQ_SPARSE: no third size)
 constexpr int SYNC_WG = KPEG_SYNC_WG;          // threads per workgroup of K1 and K2
 constexpr int SYNC_PASSES = 3;   // sync kernels enqueued per call: pass 0, the verifying pass 1, the chained pass (+ scan of the totals)
 #ifndef KPEG_WARM_BITS
@@ -2262,6 +2271,9 @@ static bool entropy_dense_subseq(int forced, bool sub420, uint64_t bytes, uint64
     return forced ? forced >= SUBSEQ_DENSE : (sub420 || bits >= px * 4 || (bits >= px * 3 && px >= (4u << 20)) || (bits * 4 >= px * 9 && bytes > 6900000u));
 }
 
+#ifndef KPEG_SMALL_MAX_BYTES
+#define KPEG_SMALL_MAX_BYTES 2200000u   // scan bytes up to which the 64-bit sub-sequences are taken (see SUBSEQ_SMALL)
+#endif
 static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, const EntropyLaunch& L, hipEvent_t* ev, bool* ev_rec,
                                  std::string* err)
 {
@@ -2272,8 +2284,14 @@ static int entropy_decode_launch(EntropyScratch* S, const EntropyTables& tabs, c
     // (from 3 bits per pixel on pictures of 4 Mpixel and more, where somewhere a chain of rounds is long; from 4 on small ones:
     // lena.jpg, 512 x 512 at 3.2 bits per pixel, takes 0.15 ms with the short sub-sequences and 0.19 ms with the long ones)
     const bool dense = entropy_dense_subseq(L.subseq, L.sub420 != 0, bytes, L.sub420 ? (uint64_t)L.nmcu * 4 : (uint64_t)L.nmcu);   // (a 4:2:0 MCU is 256 pixels)
-    return dense ? entropy_decode_launch_s<SUBSEQ_DENSE>(S, tabs, L, ev, ev_rec, err)
-                 : entropy_decode_launch_s<SUBSEQ_SPARSE>(S, tabs, L, ev, ev_rec, err);
+    if (dense) return entropy_decode_launch_s<SUBSEQ_DENSE>(S, tabs, L, ev, ev_rec, err);
+    if constexpr (SUBSEQ_SMALL < SUBSEQ_SPARSE) {
+        // one small picture below 2.5 bits per pixel (a batch is one long stream, however small its pictures; restart segments keep K0)
+        const uint64_t bits = bytes * 8, px = (uint64_t)L.nmcu * 64;
+        const bool small = L.subseq ? L.subseq == SUBSEQ_SMALL : (!L.nimg && !L.restart_interval && bytes <= KPEG_SMALL_MAX_BYTES && bits * 2 < px * 5);
+        if (small) return entropy_decode_launch_s<SUBSEQ_SMALL>(S, tabs, L, ev, ev_rec, err);
+    }
+    return entropy_decode_launch_s<SUBSEQ_SPARSE>(S, tabs, L, ev, ev_rec, err);
 }
 
 }  // namespace kpeg_dev

@@ -1260,8 +1260,8 @@ extern "C" int kpeg_hip_decode_sharded_dev(kpeg_hip_ctx* const* ctxs, int ngpu, 
 }
 
 // test hook: key 1 = number of sync passes enqueued (0 = default), key 2 = K1's warm-up sub-sequences (< 0 = default),
-// key 3 = images per fused-batch chunk (0 = default), key 4 = sub-sequence size (0 = from the bit rate, else the sparse or the
-// dense size is forced), key 5 = bound of the device-side waits between workgroups in microseconds (0 = defaults), key 6 = fault
+// key 3 = images per fused-batch chunk (0 = default), key 4 = sub-sequence size (0 = from the bit rate and the picture's size, else forced: 64 = the small
+// pictures', >= 384 the dense one, anything else the sparse one), key 5 = bound of the device-side waits between workgroups in microseconds (0 = defaults), key 6 = fault
 // injection: bit 0 K0's, bit 1 the chained K1 pass's first workgroup never publishes (its successors must time out), bit 2 K0 publishes no
 // aggregates, bit 3 every third workgroup of k_sync_write gives the call up (the kernel's second launch then decodes it), key 7 = coefficient
 // layout between K2 and K4: 0 = chosen per call, 1 = always dense, 2 = the compact stream wherever it is possible, key 8 = K0 even

@@ -278,7 +278,7 @@ def test_the_second_launch_of_k_sync_write_finishes_a_call_the_first_gives_up(ct
             assert st == T.DECODE_DONE
             rc, frame, scan = K.host_parse(data)
             assert rc == K.DECODE_DONE
-            for subseq in (0, 384):
+            for subseq in (0, 64, 384):
                 for warm in (-1, 0):
                     assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, subseq) == 0
                     assert ctx.lib.kpeg_hip_debug_set(ctx._h, 2, warm) == 0

@@ -63,10 +63,11 @@ def test_extreme_geometries(ctx, w, h):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("subseq", [0, 96, 384])
+@pytest.mark.parametrize("subseq", [0, 64, 96, 384])
 def test_random_sweep_against_the_oracle(ctx, subseq):
     """Seeded sweep over sizes, qualities, noise levels, dense-noise mode and restart intervals (48 cases), with
-    K1/K2's sub-sequence size chosen from the bit rate (0) and forced to the sparse and the dense size."""
+    K1/K2's sub-sequence size chosen from the bit rate and the picture's size (0) and forced to the small pictures', the sparse and
+    the dense size."""
     assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, subseq) == 0
     try:
         _random_sweep(ctx)

@@ -56,7 +56,7 @@ def test_photographs_match_the_reference_ppm(ctx, name):
     assert sha(data) == g["jpg_sha256"]
     rc, frame, scan = K.host_parse(data)
     assert rc == K.DECODE_DONE
-    for subseq in (0, 96, 384):
+    for subseq in (0, 64, 96, 384):
         assert ctx.lib.kpeg_hip_debug_set(ctx._h, 4, subseq) == 0
         try:
             rgb = ctx.decode_scan(frame, scan)
