@@ -5,6 +5,7 @@
 // must execute the reference's float/double operations one by one.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1145,14 +1146,39 @@ static int decode_sharded_impl(kpeg_hip_ctx* const* ctxs, int ngpu, const kpeg_f
         // RSTn positions in the still-stuffed scan: FF D0..D7 cannot occur inside entropy-coded data.  memchr finds the FF bytes
         // (one in ~200 bytes of a q75 stream) at memory speed: 35 MB of the 16384 x 16384 image in a few ms, where a byte loop took tens.
         const uint64_t nint = ((uint64_t)mw * mh + f->restart_interval - 1) / f->restart_interval;
+        // ... and in slices, one host thread each (the 35 MB are 3 ms for one thread -- longer than eight GPUs take to decode them): a marker
+        // belongs to the slice its FF lies in (the byte behind it may be the next slice's first: it is read, not scanned, there)
+        const auto t_scan0 = std::chrono::steady_clock::now();
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t nsl = std::max<size_t>(1, std::min<size_t>({(size_t)hw, (size_t)16, scan_len / ((size_t)1 << 20)}));
+        std::vector<std::vector<size_t>> found(nsl);
+        auto scan_slice = [&](size_t k) {
+            const uint8_t* const lim = scan + scan_len - 1;   // (the last byte cannot start a marker)
+            const uint8_t* q = scan + scan_len * k / nsl;
+            const uint8_t* const end = std::min(lim, scan + scan_len * (k + 1) / nsl);
+            std::vector<size_t>& out = found[k];
+            out.reserve((size_t)(nint / nsl + 16));
+            while (q < end) {
+                q = static_cast<const uint8_t*>(std::memchr(q, 0xFF, (size_t)(end - q)));
+                if (!q) break;
+                if (q[1] >= 0xD0 && q[1] <= 0xD7) out.push_back((size_t)(q - scan));
+                ++q;
+            }
+        };
+        if (nsl == 1) {
+            scan_slice(0);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t k = 1; k < nsl; ++k) th.emplace_back(scan_slice, k);
+            scan_slice(0);
+            for (auto& t : th) t.join();
+        }
         std::vector<size_t> rst;
         rst.reserve((size_t)nint);
-        for (const uint8_t* q = scan, *end = scan + scan_len - 1; q < end;) {
-            q = static_cast<const uint8_t*>(std::memchr(q, 0xFF, (size_t)(end - q)));
-            if (!q) break;
-            if (q[1] >= 0xD0 && q[1] <= 0xD7) rst.push_back((size_t)(q - scan));
-            ++q;
-        }
+        for (const auto& v : found) rst.insert(rst.end(), v.begin(), v.end());
+        if (std::getenv("KPEG_DEBUG"))
+            std::fprintf(stderr, "kpeg_hip: restart-marker scan of %zu bytes: %zu markers, %zu host threads, %.3f ms\n", scan_len, rst.size(), nsl,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan0).count());
         if (rst.size() + 1 != nint) {
             root->last_error = "restart markers do not match the restart interval";
             return KPEG_HIP_E_STREAM;
