@@ -1115,6 +1115,14 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
     if constexpr (COMPACT)
         if (tilek_next < wg_ntiles) tile_records(tilek_next, rs_next, rn_next);
     for (;;) {
+        // The tile's memory phase (hand-out, rebuild of the blocks in LDS, the next tile's loads, the previous tile's write-back) is issued
+        // ahead of the other wavefronts' arithmetic: whoever has latencies to start starts them first.  0.8 us of K4 (profiles/r03_m_k4_wave_priority_ab.txt;
+        // the other way round -- the arithmetic first -- costs 3).
+#ifndef KPEG_K4_PRIO_MEM
+#define KPEG_K4_PRIO_MEM 2
+#define KPEG_K4_PRIO_ALU 0
+#endif
+        __builtin_amdgcn_s_setprio(KPEG_K4_PRIO_MEM);
         const uint32_t tilek = tilek_cur;              // this tile's number inside the workgroup's range
         if (!(tilek < wg_ntiles)) break;               // wave-uniform
         const uint32_t tile = tile_of(tilek);
@@ -1174,6 +1182,7 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
         // (same floats as the full transform, see row_idct8).  8K q75: luma 6x6 for 98 % of the tiles, chroma 4x4 for 99 %.
         // All four wave-uniform conditions of a tile are taken together, ahead of the first branch on any of them: a scalar
         // branch on a vector compare stalls the wavefront until the compare has left the vector pipe, once instead of four times.
+        __builtin_amdgcn_s_setprio(KPEG_K4_PRIO_ALU);
         const bool big0 = __ballot((d0.w | (u >= 6 ? (d0.x | d0.y | d0.z) : 0u)) != 0) != 0;
         const bool big1 = __ballot(((d1.z | d1.w) | (u >= 4 ? (d1.x | d1.y) : 0u)) != 0) != 0;
         const bool big2 = __ballot(((d2.z | d2.w) | (u >= 4 ? (d2.x | d2.y) : 0u)) != 0) != 0;
