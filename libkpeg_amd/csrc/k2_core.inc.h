@@ -89,7 +89,7 @@
     if (valid) {
         const uint32_t seg_mcu0 = a.interval ? g.seg * a.interval : 0;
         const uint32_t seg_mcus = a.interval ? min(a.interval, a.nmcu - seg_mcu0) : a.nmcu;
-        const bool gray = !COMPACT && !S420 && a.gray != 0;     // one block per MCU, stored as the MCU's luma block (stride 3); dense layout only
+        const bool gray = !S420 && a.gray != 0;     // one block per MCU, stored as the MCU's luma block (stride 3; compact stream: the records' block numbers and the DC values likewise, the chroma blocks' DC values are zeroed by the host)
         const uint32_t bstride = gray ? 3u : 1u;
         constexpr uint32_t BPM = S420 ? 6u : 3u;       // blocks per MCU (4:2:0, extension: Y Y Y Y Cb Cr)
         const uint32_t blk_limit = gray ? seg_mcus : seg_mcus * BPM;   // blocks of this segment
@@ -128,10 +128,10 @@
         if (COMPACT) {
             ord = wrec_g + s_prer[threadIdx.x];
             ord_end = min(ord + nrec_i, a.rec_cap);
-            const uint32_t gbn = seg_mcu0 * 3 + b;
+            const uint32_t gbn = seg_mcu0 * 3 + b * bstride;
             tn = gbn / TILE_BLOCKS;
             bmn = gbn - tn * TILE_BLOCKS;
-            bm_cur = bmn ? bmn - 1 : TILE_BLOCKS - 1;   // the block in progress at entry (if any)
+            bm_cur = bmn ? bmn - bstride : TILE_BLOCKS - bstride;   // the block in progress at entry (if any)
         }
         float Asum = 0.0f;      // K4's error bound for this block: A = sum |in|, nnz = non-zero AC terms (idct_colour.hip.h)
         int nnz = 0;
@@ -193,8 +193,8 @@
                 if (COMPACT) {
                     bm_cur = bmn;
                     if (bmn == 0 && tn <= a.ntiles) a.tile_start[tn] = ord;   // this tile's records begin here
-                    bmn++;
-                    if (bmn == TILE_BLOCKS) {
+                    bmn += bstride;
+                    if (bmn == TILE_BLOCKS) {   // (TILE_BLOCKS is a multiple of the stride)
                         bmn = 0;
                         tn++;
                     }

@@ -518,7 +518,7 @@ extern "C" int kpeg_hip_idct_colour(kpeg_hip_ctx* ctx, const kpeg_frame* f, cons
 // tiles (width a multiple of 64), and never for the reference-order cross-check kernel, which reads dense blocks.
 static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t scan_bytes, uint64_t nmcu)
 {
-    if (ctx->coef_layout == 1 || ctx->idct_mode == 1 || f->components == 1 || f->components == KPEG_FRAME_420) return false;
+    if (ctx->coef_layout == 1 || ctx->idct_mode == 1 || f->components == KPEG_FRAME_420) return false;   // (grayscale since the end of round 3: its one block per MCU takes the luma block's place in the stream, through the separate launches)
     if ((f->width / 8) % TILE_MCUS != 0) return false;
     const bool dense = entropy_dense_subseq(ctx->subseq, f->components == KPEG_FRAME_420, scan_bytes, nmcu);   // (the launcher's own rule)
     if (ctx->coef_layout == 2) return true;
@@ -535,7 +535,9 @@ static bool want_compact(const kpeg_hip_ctx* ctx, const kpeg_frame* f, uint64_t 
     // all launch gaps and latency chains: 512x512 ... 2560x1440 synthetic 4-9 % faster, lena.jpg the same, a 640x424 photograph at
     // 3.5 bit/px 0.162 -> 0.145 ms; with the long sub-sequences (from 4 bits per pixel there) the dense layout stays ahead by 2 %
     // (tools/small_images_layout.py, profiles/r03_l_small_pictures_layout.txt).
-    if (nmcu * 384 <= ((uint64_t)32 << 20)) return !dense;
+    // (grayscale has no one kernel to gain there: k_write and K4 are 10-25 % slower on a 1080p picture with the records than with the
+    // dense blocks, tools/experiments/gray_layout_check.py)
+    if (nmcu * 384 <= ((uint64_t)32 << 20)) return !dense && f->components != 1;
     return !dense || scan_bytes * 8 < nmcu * 64 * 5;
 }
 
@@ -577,6 +579,8 @@ static int run_entropy(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_
         L.d_rec = (uint32_t*)ctx->d_rec;
         L.rec_cap = (uint32_t)std::min<uint64_t>(nrec, 0xFFFFFFFFu);
         L.d_dc16 = (int16_t*)ctx->d_dc16;
+        // grayscale: K2 writes the luma blocks' DC values only; the chroma blocks' (no records, bound "exact") read as zero
+        if (f->components == 1) HIPCHK(ctx, hipMemsetAsync(ctx->d_dc16, 0, (size_t)nmcu * 3 * 2, ctx->stream));
         L.d_tile_start = (uint32_t*)ctx->d_tstart;
         L.ntiles = nmcu / TILE_MCUS;
     }

@@ -35,7 +35,7 @@ def test_fixtures_match_the_oracle(ctx, name):
     data = open(os.path.join(GOLD, name), "rb").read()
     st, want = T.oracle_decode_gray(data)
     assert st == T.DECODE_DONE and T.sha256(want.tobytes()) == MAN[name]["oracle_rgb_sha256"]
-    for layout in (0, 1, 2):        # 2 = compact asked for: one-component frames stay on the dense layout
+    for layout in (0, 1, 2):        # 2 = the compact stream wherever the width allows it (one-component frames too, since the end of round 3)
         assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, layout) == 0
         got, _, _ = _decode(ctx, data, "rst" in name)
         bad = np.argwhere(got != want)
@@ -60,10 +60,15 @@ def test_pillow_encodings_match_the_oracle(ctx, w, h, q, kw):
     data = buf.getvalue()
     st, want = T.oracle_decode_gray(data)
     assert st == T.DECODE_DONE
-    got, _, _ = _decode(ctx, data, bool(kw.get("restart_marker_rows") or kw.get("restart_marker_blocks")))
-    bad = np.argwhere(got != want)
-    assert bad.size == 0, "first mismatches (y,x,c) %s of %d" % (bad[:8].tolist(), len(bad))
-    assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+    for layout in (0, 1, 2):        # the library's choice, the dense coefficients, the compact stream wherever the width allows it
+        assert ctx.lib.kpeg_hip_debug_set(ctx._h, 7, layout) == 0
+        try:
+            got, _, _ = _decode(ctx, data, bool(kw.get("restart_marker_rows") or kw.get("restart_marker_blocks")))
+        finally:
+            ctx.lib.kpeg_hip_debug_set(ctx._h, 7, 0)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, "layout %d: first mismatches (y,x,c) %s of %d" % (layout, bad[:8].tolist(), len(bad))
+        assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
 
 
 def test_gray_then_colour_then_gray_on_one_context(ctx):

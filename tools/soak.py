@@ -47,6 +47,9 @@ def main():
                 w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
                 if kind == "gray":      # the grayscale oracle wants whole blocks
                     w, h = ((w + 7) & ~7), ((h + 7) & ~7)
+                    if rng.random() < 0.5:
+                        w = max(64, w & ~63)    # whole K4 tiles: the compact stream is possible (layout 2 asks for it)
+                    ctx.lib.kpeg_hip_debug_set(ctx._h, 7, int(rng.choice([0, 1, 2])))
                 y, x = np.mgrid[0:h, 0:w]
                 px = np.stack([(x * 3 + y) % 256, (y * 2) % 256, (x + y * 5) % 256], -1) * float(rng.random()) + rng.normal(128, float(rng.choice([1, 10, 40])), (h, w, 3)) * float(rng.random())
                 px = np.clip(px, 0, 255).astype(np.uint8)
