@@ -1276,6 +1276,9 @@ __global__ __launch_bounds__(K4_THREADS) KPEG_K4_OCC void k_idct_colour_fast(Idc
                 const float ka = fabsf((tc - t) - 0.5f) - (0.5f - KPEG_G_DELTA);                // >= 0: within DELTA of an integer
                 const float kb = __builtin_fmaf(fabsf(t), 131072.0f, KPEG_G_DELTA - 1.0f);      // >= 0: t != 0
                 uint32_t kg = __float_as_uint(ka) | __float_as_uint(kb);                         // sign clear: G is unsafe
+#ifdef KPEG_ABLATE_GKEY
+                kg = 0x80000000u;   // timing experiment: no G key (wrong on 36 chroma pairs)
+#endif
 #endif
                 if (decltype(with_wide)::value) {
                     if (wide) {
