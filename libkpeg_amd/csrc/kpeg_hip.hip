@@ -481,7 +481,7 @@ extern "C" int kpeg_hip_idct_colour_dev(kpeg_hip_ctx* ctx, const kpeg_frame* f, 
         // caller-supplied coefficients carry no error bounds: derive them (K2 does this on the decode path)
         QTables qt;
         natural_qtables(f, &qt);
-        hipLaunchKernelGGL(k_ebound, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, d_coef, nblocks, qt,
+        hipLaunchKernelGGL(k_ebound, dim3((nblocks + EB_BLOCKS - 1) / EB_BLOCKS), dim3(256), 0, ctx->stream, d_coef, nblocks, qt,
                            (float*)ctx->d_ebound);
     }
     mark(ctx, kpeg_hip_ctx::EV_DC);
