@@ -692,6 +692,15 @@ __global__ void k_crop(const uint8_t* __restrict__ src, uint32_t spitch, uint8_t
     if (i >= total) return;
     uint32_t y = (uint32_t)(i / dpitch), x = (uint32_t)(i - (uint64_t)y * dpitch), w = 0;
     const uint32_t nb = (uint32_t)(total - i < 4 ? total - i : 4);
+    if (nb == 4 && x + 4 <= dpitch) {
+        // the four bytes lie in one row: two aligned words of the source and a funnel shift instead of four byte loads (the word
+        // behind a row's last may be the next row's or the buffer's slack: read, and shifted out) -- 12 Mpixel: 34 -> 21 us
+        const size_t s = (size_t)y * spitch + x;
+        const uint32_t* const s32 = reinterpret_cast<const uint32_t*>(src + (s & ~(size_t)3));   // (src is 16-byte aligned: a context's own scratch)
+        const uint32_t lo = s32[0], hi = (s & 3) ? s32[1] : 0u;
+        *reinterpret_cast<uint32_t*>(dst + i) = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(s & 3));   // (dst is 8-byte aligned: launch_idct's rule for every destination)
+        return;
+    }
     for (uint32_t k = 0; k < nb; ++k) {
         if (x == dpitch) {
             x = 0;
@@ -701,7 +710,7 @@ __global__ void k_crop(const uint8_t* __restrict__ src, uint32_t spitch, uint8_t
         x++;
     }
     if (nb == 4) {
-        *reinterpret_cast<uint32_t*>(dst + i) = w;   // (dst is 8-byte aligned: launch_idct's rule for every destination)
+        *reinterpret_cast<uint32_t*>(dst + i) = w;
     } else {
         for (uint32_t k = 0; k < nb; ++k) dst[i + k] = (uint8_t)(w >> (8 * k));
     }
