@@ -21,8 +21,10 @@ namespace kpeg
         std::size_t groups = 0;     ///< calls into the GPU path (groups of identical geometry and tables)
     };
 
-    /// `names`: files, or directories (their *.jpg entries are taken in name order).
-    BatchResult decodeFiles( const std::vector<std::string>& names, bool allowDRI = false );
+    /// `names`: files, or directories (their *.jpg entries are taken in name order).  The flags are JPEGDecoder's extensions
+    /// (setRestartMarkerSupport, setGrayscaleSupport, setAnySizeSupport, set420Support), all off by default.
+    BatchResult decodeFiles( const std::vector<std::string>& names, bool allowDRI = false, bool allowGray = false, bool allowAnySize = false,
+                             bool allow420 = false );
 }
 
 #endif

@@ -66,7 +66,7 @@ namespace kpeg
         }
     }
 
-    BatchResult decodeFiles( const std::vector<std::string>& names, bool allowDRI )
+    BatchResult decodeFiles( const std::vector<std::string>& names, bool allowDRI, bool allowGray, bool allowAnySize, bool allow420 )
     {
         BatchResult res;
         std::vector<std::string> files;
@@ -86,6 +86,9 @@ namespace kpeg
             Item it;
             it.dec.reset( new JPEGDecoder );
             it.dec->setRestartMarkerSupport( allowDRI );
+            it.dec->setGrayscaleSupport( allowGray );
+            it.dec->setAnySizeSupport( allowAnySize );
+            it.dec->set420Support( allow420 );
             it.dec->setParseOnly( true );
             if ( !it.dec->open( name ) || it.dec->decodeImageFile() != JPEGDecoder::DECODE_DONE || !it.dec->decodable() ||
                  !it.dec->frameInfo( &it.frame ) )

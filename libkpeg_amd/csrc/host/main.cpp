@@ -27,7 +27,7 @@ static void printHelp()
     std::cout << "Help\n" << std::endl;
     std::cout << "<filename.jpg>                  : Decompress a JPEG image to a PPM image" << std::endl;
     std::cout << "--allow-dri <filename.jpg>      : same, accepting restart markers (extension)" << std::endl;
-    std::cout << "--batch [--allow-dri] <files and directories...> : Decompress many JPEG images (extension)" << std::endl;
+    std::cout << "--batch [--allow-dri] [--allow-gray] [--allow-any-size] [--allow-420] <files and directories...> : Decompress many JPEG images (extension)" << std::endl;
     std::cout << "--allow-gray <filename.jpg>     : ... accepting one-component (grayscale) files (extension)" << std::endl;
     std::cout << "--allow-any-size <filename.jpg> : ... accepting widths and heights that are not multiples of 8 (extension)" << std::endl;
     std::cout << "--allow-420 <filename.jpg>      : ... accepting 4:2:0 files of any size (extension)" << std::endl;
@@ -83,17 +83,24 @@ int main( int argc, char** argv )
         }
         if ( argc >= 3 && std::string( argv[1] ) == "--batch" )
         {
-            bool allowDRI = false;
+            bool allowDRI = false, allowGray = false, allowAnySize = false, allow420 = false;
             std::vector<std::string> names;
             for ( int i = 2; i < argc; ++i )
             {
-                if ( std::string( argv[i] ) == "--allow-dri" )
+                const std::string arg( argv[i] );
+                if ( arg == "--allow-dri" )
                     allowDRI = true;
+                else if ( arg == "--allow-gray" )
+                    allowGray = true;
+                else if ( arg == "--allow-any-size" )
+                    allowAnySize = true;
+                else if ( arg == "--allow-420" )
+                    allow420 = true;
                 else
-                    names.push_back( argv[i] );
+                    names.push_back( arg );
             }
             kpeg::Logger::get().setLevel( kpeg::Logger::Level::ERROR );   // one INFO line per marker and file is too much here
-            const kpeg::BatchResult r = kpeg::decodeFiles( names, allowDRI );
+            const kpeg::BatchResult r = kpeg::decodeFiles( names, allowDRI, allowGray, allowAnySize, allow420 );
             std::cout << "kpeg --batch: " << r.written << " PPM written, " << r.rejected << " rejected, " << r.failed
                       << " failed, " << r.groups << " group(s)" << std::endl;
             return r.failed ? EXIT_FAILURE : EXIT_SUCCESS;

@@ -379,6 +379,43 @@ def test_cli_batch_front_end(tmp_path):
     assert not os.path.exists(d / "a9_corrupt.ppm") and not os.path.exists(d / "rej_dri.ppm") and not os.path.exists(d / "note.ppm")
 
 
+def test_cli_batch_front_end_with_the_extensions(tmp_path):
+    """`kpeg --batch --allow-any-size --allow-420 --allow-gray <dir>`: pictures whose sizes are no multiples of 8 (a group of three of one
+    geometry: the fused batch path into scratch, a crop per picture), 4:2:0 pictures (a group of two: picture by picture) and a grayscale
+    one; every PPM is the oracle's; without the flags the same call writes nothing."""
+    import io, subprocess
+    Image = pytest.importorskip("PIL.Image")
+    import libkpeg_amd as K
+    d = tmp_path / "in"
+    d.mkdir()
+    rng = np.random.default_rng(12)
+    want = {}
+    y, x = np.mgrid[0:75, 0:101]
+    for k in range(3):
+        px = np.clip(np.stack([(x * (k + 2)) % 256, (y * 3) % 256, (x + y + 9 * k) % 256], -1) * 0.7 + rng.normal(40, 6, (75, 101, 3)), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(px).save(b, "JPEG", quality=80, subsampling=0)
+        (d / ("odd%d.jpg" % k)).write_bytes(b.getvalue())
+        want["odd%d" % k] = T.ppm_header(101, 75) + T.oracle_decode_any_size(b.getvalue())[1].tobytes()
+    for k in range(2):
+        px = np.clip(rng.normal(120, 35, (50, 70, 3)), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(px).save(b, "JPEG", quality=85, subsampling=2)
+        (d / ("sub%d.jpg" % k)).write_bytes(b.getvalue())
+        want["sub%d" % k] = T.ppm_header(70, 50) + T.oracle_decode_420(b.getvalue())[1].tobytes()
+    b = io.BytesIO()
+    Image.fromarray(np.clip(rng.normal(128, 30, (48, 64)), 0, 255).astype(np.uint8), "L").save(b, "JPEG", quality=75)
+    (d / "gray.jpg").write_bytes(b.getvalue())
+    want["gray"] = T.ppm_header(64, 48) + T.oracle_decode_gray(b.getvalue())[1].tobytes()
+    out = subprocess.run([K.CLI, "--batch", str(d)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert "0 PPM written" in out.stdout and "6 rejected" in out.stdout, out.stdout[-800:] + out.stderr[-400:]
+    out = subprocess.run([K.CLI, "--batch", "--allow-any-size", "--allow-420", "--allow-gray", str(d)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert "6 PPM written" in out.stdout and "0 rejected" in out.stdout and "0 failed" in out.stdout, out.stdout[-800:] + out.stderr[-400:]
+    assert out.returncode == 0
+    for name, ppm in want.items():
+        assert open(d / (name + ".ppm"), "rb").read() == ppm, name
+
+
 def test_full_size_8k_properties(ctx):
     """BASELINE's full size (7680x4320): too slow for the scalar oracle in a unit test budget beyond one
     pass, so check it once against the multi-threaded oracle and by a checksum of row checksums."""
