@@ -745,20 +745,24 @@ static int decode_420(kpeg_hip_ctx* ctx, const kpeg_frame* f, const uint8_t* d_s
     if (rc) return rc;
     QTables qt;
     natural_qtables(f, &qt);
+    // a picture of whole MCUs needs no crop: the pixel kernel writes the caller's buffer
+    const bool whole = (f->width & 15) == 0 && (f->height & 15) == 0;
+    uint8_t* const out = whole ? d_rgb : (uint8_t*)ctx->d_pad;
     if (ctx->idct_mode == 1) {
         // cross-check: every sample in the reference's order
-        hipLaunchKernelGGL(k_idct_colour_exact_420, dim3((unsigned)nmcu), dim3(256), 0, ctx->stream, (const int16_t*)ctx->d_coef, (uint8_t*)ctx->d_pad,
-                           mw, mw * 48, qt);
+        hipLaunchKernelGGL(k_idct_colour_exact_420, dim3((unsigned)nmcu), dim3(256), 0, ctx->stream, (const int16_t*)ctx->d_coef, out, mw, mw * 48, qt);
     } else {
         Idct420Params p;
-        p.coef = (const int16_t*)ctx->d_coef, p.ebound = (const float*)ctx->d_ebound, p.rgb = (uint8_t*)ctx->d_pad;
+        p.coef = (const int16_t*)ctx->d_coef, p.ebound = (const float*)ctx->d_ebound, p.rgb = out;
         p.mcus_w = mw, p.mcus_h = mh, p.pitch = mw * 48, p.tiles_w = (mw + 3) / 4, p.ntiles = p.tiles_w * mh;
         p.stats = ctx->d_status + 16;
         hipLaunchKernelGGL(k_idct_colour_fast_420, dim3((p.ntiles + 3) / 4), dim3(256), 0, ctx->stream, p, qt);
     }
-    const uint64_t total = (uint64_t)f->width * f->height * 3;
-    hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_pad, mw * 48, d_rgb,
-                       f->width * 3, total);
+    if (!whole) {
+        const uint64_t total = (uint64_t)f->width * f->height * 3;
+        hipLaunchKernelGGL(k_crop, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_pad, mw * 48, d_rgb,
+                           f->width * 3, total);
+    }
     HIPCHK(ctx, hipGetLastError());
     mark(ctx, kpeg_hip_ctx::EV_IDCT);
     return finish_async(ctx, false);

@@ -33,7 +33,7 @@ def _check(ctx, data, dri=False):
     return frame, scan, want
 
 
-@pytest.mark.parametrize("w,h,q,kw", [(16, 16, 75, {}), (1, 1, 80, {}), (17, 9, 90, {}), (640, 424, 90, {}), (333, 201, 50, {"optimize": True}),
+@pytest.mark.parametrize("w,h,q,kw", [(16, 16, 75, {}), (1, 1, 80, {}), (17, 9, 90, {}), (640, 424, 90, {}), (320, 208, 85, {}), (333, 201, 50, {"optimize": True}),
                                       (640, 424, 97, {}), (320, 200, 85, {"restart_marker_blocks": 3}), (640, 400, 75, {"restart_marker_rows": 1})])
 def test_photograph_crops_match_the_oracle(ctx, w, h, q, kw):
     """One MCU to 0.27 Mpixel, sparse and dense streams, optimised tables,
@@ -43,7 +43,7 @@ def test_photograph_crops_match_the_oracle(ctx, w, h, q, kw):
     _check(ctx, data, bool(kw.get("restart_marker_blocks") or kw.get("restart_marker_rows")))
 
 
-@pytest.mark.parametrize("w,h", [(1920, 1080), (4000, 3000)])
+@pytest.mark.parametrize("w,h", [(1920, 1080), (2048, 1536), (4000, 3000)])   # (2048 x 1536: whole MCUs, the pixel kernel writes the caller's buffer, no crop)
 def test_large_synthetic_pictures_match_the_oracle(ctx, w, h):
     """Millions of pixels: many K1/K2 workgroups, blocks and MCUs split across sub-sequences and workgroups, flat parts
     (quirk Q1 blocks), saturated colour edges."""
